@@ -1,0 +1,503 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the product path
+ * (arap_flow_amd/).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * CPU restatement of the reference's ARAP Gauss-Newton / PCG solve, instantiated twice by
+ * arap_oracle.c (REAL = float -> suffix _f32, REAL = double -> suffix _f64).
+ *
+ * Every function cites the reference file:line (paths relative to /root/reference) it follows.
+ * The reference emits its kernels at run time from a symbolic-AD compiler (ARAP/API/src/o.t), so
+ * evalJTF / applyJTJ / cost below are the closed forms of what o.t:2129-2172, o.t:2029-2089 and
+ * o.t:2375-2385 generate for the energy in arap_plan.t:1-23.  tests/test_oracle.py pins those
+ * closed forms against a finite-difference Jacobian of the residuals (this file's
+ * oracle_residuals_*) and pins the whole schedule against the reference's golden vector
+ * ARAP/warping/cat512_iFlo.flo.
+ *
+ * Layout (o.t:376-387): row major, x fastest, index = x + W*y, channels interleaved.
+ *   O, U, C : REAL[N][2]      A, M : REAL[N]      3-vectors (delta, r, p, ...) : REAL[N][3] = (Ox,Oy,A)
+ */
+
+#ifndef REAL
+#error "include from arap_oracle.c with REAL and SUF defined"
+#endif
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SUF)
+
+/* reduction mode for the three PCG dot products and the cost:
+ *   0 : accumulate in REAL, sequentially in index order (one fixed instance of the order the
+ *       reference leaves undefined: warp shuffle + atomicAdd, solverGPUGaussNewton.t:312-317)
+ *   1 : per-vertex term evaluated in REAL, accumulated in double ("f32sum64" of SURVEY 8c).
+ *       Order independent to ~1e-16, which is what the HIP path implements. */
+typedef struct {
+    int W, H;
+    const REAL *U;   /* UrShape     [N][2]  arap_plan.t:4 */
+    const REAL *C;   /* Constraints [N][2]  arap_plan.t:5 */
+    const REAL *M;   /* Mask        [N]     arap_plan.t:6 */
+    REAL wf, wr;     /* w_fitSqrt, w_regSqrt  arap_plan.t:7-8 */
+    int trig;        /* 0: libm cos/sin, 1: arap_sincos_spec (bit-twin of the HIP routine) */
+} FN(Prob);
+
+/* stencil order of arap_plan.t:14 */
+static const int FN(SX)[4] = {1, -1, 0, 0};
+static const int FN(SY)[4] = {0, 0, 1, -1};
+
+static inline void FN(sincos_)(const FN(Prob) * pb, REAL a, REAL *c, REAL *s)
+{
+    if (pb->trig == 1) {
+        double cd, sd;
+        arap_sincos_spec((double)a, &cd, &sd);
+        *c = (REAL)cd;
+        *s = (REAL)sd;
+    } else if (sizeof(REAL) == 4) {
+        *c = (REAL)cosf((float)a);
+        *s = (REAL)sinf((float)a);
+    } else {
+        *c = (REAL)cos((double)a);
+        *s = (REAL)sin((double)a);
+    }
+}
+
+/* Exclude(Not(eq(Mask(0,0),0)))  arap_plan.t:11 */
+static inline int FN(act)(const FN(Prob) * pb, int i) { return pb->M[i] == (REAL)0; }
+
+/* valid = InBounds(x,y) * eq(Mask(x,y),0) * eq(Mask(0,0),0)   arap_plan.t:17
+ * (centre always in bounds: o.t:1930-1934; out-of-bounds reads give 0: o.t:570-576) */
+static inline int FN(edge)(const FN(Prob) * pb, int x, int y, int s, int *n)
+{
+    int nx = x + FN(SX)[s], ny = y + FN(SY)[s];
+    if (nx < 0 || nx >= pb->W || ny < 0 || ny >= pb->H) return 0;
+    *n = nx + pb->W * ny;
+    return FN(act)(pb, x + pb->W * y) && FN(act)(pb, *n);
+}
+
+/* valid = All(greatereq(Constraints(0,0),0))   arap_plan.t:22, lib.t:13-19 */
+static inline int FN(fit)(const FN(Prob) * pb, int i)
+{
+    return pb->C[2 * i] >= (REAL)0 && pb->C[2 * i + 1] >= (REAL)0;
+}
+
+/* Reductions are evaluated as per-row partial sums (x ascending) combined in row order, so the
+ * result does not depend on the OpenMP thread count. */
+static double FN(combine_rows)(const double *rowd, const REAL *rowr, int H, int mode)
+{
+    if (mode == 1) { double a = 0.0; for (int y = 0; y < H; ++y) a += rowd[y]; return (double)(REAL)a; }
+    REAL a = (REAL)0; for (int y = 0; y < H; ++y) a = a + rowr[y]; return (double)a;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * residuals, arap_plan.t:14-23 :  e_s(c) = w_r[(O(c)-O(n)) - R(A(c))(U(c)-U(n))],  f(c) = w_f(O(c)-C(c))
+ * Rotate2D: lib.t:92-96.  out[N][10] = e_0.xy, e_1.xy, e_2.xy, e_3.xy, f.xy (0 where invalid or
+ * where the centre is excluded).  Used for the cost and by the finite-difference pin test.
+ * ------------------------------------------------------------------------------------------- */
+static void FN(residuals_at)(const FN(Prob) * pb, const REAL *O, const REAL *A, int x, int y, REAL out[10])
+{
+    int i = x + pb->W * y, n;
+    for (int k = 0; k < 10; ++k) out[k] = (REAL)0;
+    if (!FN(act)(pb, i)) return;
+    REAL c, s;
+    FN(sincos_)(pb, A[i], &c, &s);
+    for (int k = 0; k < 4; ++k) {
+        if (!FN(edge)(pb, x, y, k, &n)) continue;
+        REAL dx = pb->U[2 * i] - pb->U[2 * n], dy = pb->U[2 * i + 1] - pb->U[2 * n + 1];
+        REAL rx = c * dx - s * dy, ry = s * dx + c * dy;
+        out[2 * k] = pb->wr * ((O[2 * i] - O[2 * n]) - rx);
+        out[2 * k + 1] = pb->wr * ((O[2 * i + 1] - O[2 * n + 1]) - ry);
+    }
+    if (FN(fit)(pb, i)) {
+        out[8] = pb->wf * (O[2 * i] - pb->C[2 * i]);
+        out[9] = pb->wf * (O[2 * i + 1] - pb->C[2 * i + 1]);
+    }
+}
+
+void FN(oracle_residuals)(int W, int H, const REAL *O, const REAL *A, const REAL *U, const REAL *C,
+                          const REAL *M, REAL wf, REAL wr, REAL *out /* [N][10] */)
+{
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) FN(residuals_at)(&pb, O, A, x, y, out + 10 * (size_t)(x + W * y));
+}
+
+/* cost: o.t:2375-2385 (0.5 * sum of squares of the residuals centred on a vertex), excluded centres
+ * skipped (solverGPUGaussNewton.t:580-592); device float upconverted to double (:1179-1182). */
+static double FN(cost_)(const FN(Prob) * pb, const REAL *O, const REAL *A, int mode)
+{
+    int W = pb->W, H = pb->H;
+    double *rowd = (double *)calloc((size_t)H, sizeof(double));
+    REAL *rowr = (REAL *)calloc((size_t)H, sizeof(REAL));
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; ++y) {
+        double accd = 0.0;
+        REAL accr = (REAL)0;
+        for (int x = 0; x < W; ++x) {
+            if (!FN(act)(pb, x + W * y)) continue;
+            REAL e[10];
+            FN(residuals_at)(pb, O, A, x, y, e);
+            REAL t = (REAL)0;
+            for (int k = 0; k < 10; ++k) t = t + e[k] * e[k];
+            t = (REAL)0.5 * t;
+            if (mode == 1) accd += (double)t; else accr = accr + t;
+        }
+        rowd[y] = accd; rowr[y] = accr;
+    }
+    double out = FN(combine_rows)(rowd, rowr, H, mode);
+    free(rowd); free(rowr);
+    return out;
+}
+
+double FN(oracle_cost)(int W, int H, const REAL *O, const REAL *A, const REAL *U, const REAL *C,
+                       const REAL *M, REAL wf, REAL wr, int mode)
+{
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    return FN(cost_)(&pb, O, A, mode);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * evalJTF: gradient J^T F (factor 1.0) and diag(J^T J), o.t:2129-2172.  For unknown c the
+ * residuals that contain it are its own four e_s(c), its f(c), and e_{-s}(n) of each neighbour n
+ * (residualsincludingX00, o.t:2143).  Closed form: SURVEY Appendix A.
+ * ------------------------------------------------------------------------------------------- */
+static void FN(evalJTF_at)(const FN(Prob) * pb, const REAL *O, const REAL *A, int x, int y,
+                           REAL g[3], REAL d[3])
+{
+    int i = x + pb->W * y, n;
+    REAL wr = pb->wr, wf = pb->wf;
+    REAL ci, si;
+    FN(sincos_)(pb, A[i], &ci, &si);
+    REAL gx = 0, gy = 0, ga = 0, dO = 0, dA = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!FN(edge)(pb, x, y, k, &n)) continue;
+        REAL cn, sn;
+        FN(sincos_)(pb, A[n], &cn, &sn);
+        REAL dx = pb->U[2 * i] - pb->U[2 * n], dy = pb->U[2 * i + 1] - pb->U[2 * n + 1];
+        REAL ox = O[2 * i] - O[2 * n], oy = O[2 * i + 1] - O[2 * n + 1];
+        /* e_s(c) */
+        REAL ex = wr * (ox - (ci * dx - si * dy));
+        REAL ey = wr * (oy - (si * dx + ci * dy));
+        /* e_{-s}(n) = w_r[-(O(c)-O(n)) + R(A(n)) d_s(c)] */
+        REAL fx = wr * ((cn * dx - sn * dy) - ox);
+        REAL fy = wr * ((sn * dx + cn * dy) - oy);
+        /* q_s(c) = R'(A(c)) d_s(c) */
+        REAL qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
+        gx = gx + wr * (ex - fx);
+        gy = gy + wr * (ey - fy);
+        ga = ga - wr * (qx * ex + qy * ey);
+        dO = dO + (wr * wr + wr * wr);
+        dA = dA + (wr * wr) * (qx * qx + qy * qy);
+    }
+    REAL dOf = dO;
+    if (FN(fit)(pb, i)) {
+        gx = gx + wf * (wf * (O[2 * i] - pb->C[2 * i]));
+        gy = gy + wf * (wf * (O[2 * i + 1] - pb->C[2 * i + 1]));
+        dOf = dO + wf * wf;
+    }
+    g[0] = gx; g[1] = gy; g[2] = ga;
+    d[0] = dOf; d[1] = dOf; d[2] = dA;
+}
+
+void FN(oracle_evalJTF)(int W, int H, const REAL *O, const REAL *A, const REAL *U, const REAL *C,
+                        const REAL *M, REAL wf, REAL wr, REAL *g /* [N][3] */, REAL *d /* [N][3] */)
+{
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t i = (size_t)(x + W * y);
+            if (FN(act)(&pb, (int)i)) FN(evalJTF_at)(&pb, O, A, x, y, g + 3 * i, d + 3 * i);
+            else for (int k = 0; k < 3; ++k) g[3 * i + k] = d[3 * i + k] = 0;
+        }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * applyJTJ: (J^T J P)(c), factor 1.0, o.t:2029-2089; A and U frozen (they are read from the
+ * unknown images, which PCG does not touch until PCGLinearUpdate).
+ * cs[N][2] = (cos A, sin A) cached once per Gauss-Newton step by the caller.
+ * ------------------------------------------------------------------------------------------- */
+static void FN(applyJTJ_at)(const FN(Prob) * pb, const REAL *cs, const REAL *P, int x, int y, REAL out[3])
+{
+    int i = x + pb->W * y, n;
+    REAL wr2 = pb->wr * pb->wr;
+    REAL ci = cs[2 * i], si = cs[2 * i + 1];
+    REAL ax = 0, ay = 0, aa = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (!FN(edge)(pb, x, y, k, &n)) continue;
+        REAL cn = cs[2 * n], sn = cs[2 * n + 1];
+        REAL dx = pb->U[2 * i] - pb->U[2 * n], dy = pb->U[2 * i + 1] - pb->U[2 * n + 1];
+        REAL qx = -si * dx - ci * dy, qy = ci * dx - si * dy;   /* R'(A(c)) d */
+        REAL hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;   /* R'(A(n)) d */
+        REAL px = P[3 * i] - P[3 * n], py = P[3 * i + 1] - P[3 * n + 1];
+        REAL pa = P[3 * i + 2], pn = P[3 * n + 2];
+        REAL tx = px - qx * pa, ty = py - qy * pa;              /* dP - q P_A(c) */
+        ax = ax + wr2 * ((px + tx) - hx * pn);
+        ay = ay + wr2 * ((py + ty) - hy * pn);
+        aa = aa - wr2 * (qx * tx + qy * ty);
+    }
+    if (FN(fit)(pb, i)) {
+        REAL wf2 = pb->wf * pb->wf;
+        ax = ax + wf2 * P[3 * i];
+        ay = ay + wf2 * P[3 * i + 1];
+    }
+    out[0] = ax; out[1] = ay; out[2] = aa;
+}
+
+static void FN(fill_cs)(const FN(Prob) * pb, const REAL *A, REAL *cs)
+{
+    int N = pb->W * pb->H;
+    for (int i = 0; i < N; ++i) FN(sincos_)(pb, A[i], &cs[2 * i], &cs[2 * i + 1]);
+}
+
+void FN(oracle_applyJTJ)(int W, int H, const REAL *A, const REAL *U, const REAL *C, const REAL *M,
+                         REAL wf, REAL wr, const REAL *P /* [N][3] */, REAL *out /* [N][3] */)
+{
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    size_t N = (size_t)W * H;
+    REAL *cs = (REAL *)malloc(sizeof(REAL) * 2 * N);
+    FN(fill_cs)(&pb, A, cs);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t i = (size_t)(x + W * y);
+            if (FN(act)(&pb, (int)i)) FN(applyJTJ_at)(&pb, cs, P, x, y, out + 3 * i);
+            else out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = 0;
+        }
+    free(cs);
+}
+
+/* guardedInvert, CERES variant: solverGPUGaussNewton.t:323-332 (selected at :22) */
+static inline REAL FN(ginv)(REAL d)
+{
+    REAL t = (REAL)1 + (sizeof(REAL) == 4 ? (REAL)sqrtf((float)d) : (REAL)sqrt((double)d));
+    return (REAL)1 / (t * t);
+}
+
+static inline REAL FN(dot3)(const REAL *a, const REAL *b)
+{
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+}
+
+/* solver state that the reference keeps in its plan (makePlan, solverGPUGaussNewton.t:1254-1284);
+ * only the six images the GN path touches. */
+typedef struct {
+    size_t N;
+    REAL *delta, *r, *z, *p, *Ap, *pre, *cs;
+} FN(Plan);
+
+static void FN(plan_alloc)(FN(Plan) * pl, size_t N)
+{
+    pl->N = N;
+    pl->delta = (REAL *)calloc(3 * N, sizeof(REAL));
+    pl->r = (REAL *)calloc(3 * N, sizeof(REAL));
+    pl->z = (REAL *)calloc(3 * N, sizeof(REAL));
+    pl->p = (REAL *)calloc(3 * N, sizeof(REAL));
+    pl->Ap = (REAL *)calloc(3 * N, sizeof(REAL));
+    pl->pre = (REAL *)calloc(3 * N, sizeof(REAL));
+    pl->cs = (REAL *)calloc(2 * N, sizeof(REAL));
+}
+static void FN(plan_free)(FN(Plan) * pl)
+{
+    free(pl->delta); free(pl->r); free(pl->z); free(pl->p); free(pl->Ap); free(pl->pre); free(pl->cs);
+}
+
+/* One Opt_ProblemSolve (o.t:2548-2551 = init + step until 0):
+ *   init  solverGPUGaussNewton.t:956-1007   nIter = 0, prevCost = cost
+ *   step  :1016-1177                        PCGInit1, lIterations x (PCGStep1, PCGStep2, PCGStep3),
+ *                                           PCGLinearUpdate, computeCost
+ * O and A are updated in place.  costs[0] = cost at init, costs[1+k] = cost after GN step k
+ * (costs may be NULL).  Returns the final cost (Opt_ProblemCurrentCost, :1179-1182).
+ * No convergence test on the GN path (the zeta break at :1093-1102 is LM only). */
+static double FN(solve_)(const FN(Prob) * pb, FN(Plan) * pl, REAL *O, REAL *A, int nIterations,
+                         int lIterations, int mode, double *costs)
+{
+    const int W = pb->W, H = pb->H;
+    double *rowd = (double *)calloc((size_t)H, sizeof(double));
+    REAL *rowr = (REAL *)calloc((size_t)H, sizeof(REAL));
+    /* rows that contain at least one active vertex (pure speed-up: inactive vertices are skipped
+     * by every kernel of the reference, so skipping whole rows changes nothing) */
+    int y0 = H, y1 = -1;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if (FN(act)(pb, x + W * y)) { if (y < y0) y0 = y; if (y > y1) y1 = y; break; }
+    double prevCost = FN(cost_)(pb, O, A, mode);
+    if (costs) costs[0] = prevCost;
+    for (int nIter = 0; nIter < nIterations; ++nIter) {
+        /* ---- PCGInit1 (:361-397) ---- */
+        FN(fill_cs)(pb, A, pl->cs);
+        memset(rowd, 0, sizeof(double) * (size_t)H); memset(rowr, 0, sizeof(REAL) * (size_t)H);
+#pragma omp parallel for schedule(static)
+        for (int y = y0; y <= y1; ++y) {
+            double sd = 0.0; REAL sr = 0;
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)(x + W * y);
+                REAL *pre = pl->pre + 3 * i;
+                if (!FN(act)(pb, (int)i)) { pre[0] = pre[1] = pre[2] = 0; continue; }
+                REAL g[3], d[3];
+                FN(evalJTF_at)(pb, O, A, x, y, g, d);
+                REAL *r = pl->r + 3 * i, *p = pl->p + 3 * i, *dl = pl->delta + 3 * i;
+                for (int k = 0; k < 3; ++k) {
+                    dl[k] = 0;
+                    r[k] = -g[k];
+                    pre[k] = FN(ginv)(d[k]);
+                    p[k] = pre[k] * r[k];
+                }
+                REAL t = FN(dot3)(r, p);
+                if (mode == 1) sd += (double)t; else sr = sr + t;
+            }
+            rowd[y] = sd; rowr[y] = sr;
+        }
+        REAL rho = (REAL)FN(combine_rows)(rowd, rowr, H, mode);      /* scanAlphaNumerator */
+        for (int l = 0; l < lIterations; ++l) {
+            /* ---- PCGStep1 (:421-434): Ap = J^T J p ; sigma = p.Ap ---- */
+#pragma omp parallel for schedule(static)
+            for (int y = y0; y <= y1; ++y) {
+                double sd = 0.0; REAL sr = 0;
+                for (int x = 0; x < W; ++x) {
+                    size_t i = (size_t)(x + W * y);
+                    if (!FN(act)(pb, (int)i)) continue;
+                    FN(applyJTJ_at)(pb, pl->cs, pl->p, x, y, pl->Ap + 3 * i);
+                    REAL t = FN(dot3)(pl->p + 3 * i, pl->Ap + 3 * i);
+                    if (mode == 1) sd += (double)t; else sr = sr + t;
+                }
+                rowd[y] = sd; rowr[y] = sr;
+            }
+            REAL sigma = (REAL)FN(combine_rows)(rowd, rowr, H, mode); /* scanAlphaDenominator */
+            /* ---- PCGStep2 (:446-489) ---- */
+            REAL alpha = 0;
+            if (sigma > (REAL)0) alpha = rho / sigma;
+#pragma omp parallel for schedule(static)
+            for (int y = y0; y <= y1; ++y) {
+                double sd = 0.0; REAL sr = 0;
+                for (int x = 0; x < W; ++x) {
+                    size_t i = (size_t)(x + W * y);
+                    if (!FN(act)(pb, (int)i)) continue;
+                    REAL *dl = pl->delta + 3 * i, *r = pl->r + 3 * i, *z = pl->z + 3 * i;
+                    const REAL *p = pl->p + 3 * i, *Ap = pl->Ap + 3 * i, *pre = pl->pre + 3 * i;
+                    for (int k = 0; k < 3; ++k) {
+                        dl[k] = dl[k] + alpha * p[k];
+                        r[k] = r[k] - alpha * Ap[k];
+                        z[k] = pre[k] * r[k];
+                    }
+                    REAL t = FN(dot3)(z, r);
+                    if (mode == 1) sd += (double)t; else sr = sr + t;
+                }
+                rowd[y] = sd; rowr[y] = sr;
+            }
+            REAL rhoNew = (REAL)FN(combine_rows)(rowd, rowr, H, mode); /* scanBetaNumerator */
+            /* ---- PCGStep3 (:537-550) ---- */
+            REAL beta = 0;
+            if (rho > (REAL)0) beta = rhoNew / rho;
+#pragma omp parallel for schedule(static)
+            for (int y = y0; y <= y1; ++y)
+                for (int x = 0; x < W; ++x) {
+                    size_t i = (size_t)(x + W * y);
+                    if (!FN(act)(pb, (int)i)) continue;
+                    for (int k = 0; k < 3; ++k) pl->p[3 * i + k] = pl->z[3 * i + k] + beta * pl->p[3 * i + k];
+                }
+            rho = rhoNew;                                /* D2D copy alphaNum <- betaNum (:1091) */
+        }
+        /* ---- PCGLinearUpdate (:552-557) ---- */
+#pragma omp parallel for schedule(static)
+        for (int y = y0; y <= y1; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)(x + W * y);
+                if (!FN(act)(pb, (int)i)) continue;
+                O[2 * i] = O[2 * i] + pl->delta[3 * i];
+                O[2 * i + 1] = O[2 * i + 1] + pl->delta[3 * i + 1];
+                A[i] = A[i] + pl->delta[3 * i + 2];
+            }
+        prevCost = FN(cost_)(pb, O, A, mode);            /* computeCost (:1117), prevCost = newCost (:1161) */
+        if (costs) costs[1 + nIter] = prevCost;
+    }
+    free(rowd); free(rowr);
+    return prevCost;
+}
+
+double FN(oracle_solve)(int W, int H, REAL *O, REAL *A, const REAL *U, const REAL *C, const REAL *M,
+                        REAL wf, REAL wr, int nIterations, int lIterations, int mode, int trig,
+                        double *costs)
+{
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, trig};
+    FN(Plan) pl;
+    FN(plan_alloc)(&pl, (size_t)W * H);
+    double c = FN(solve_)(&pb, &pl, O, A, nIterations, lIterations, mode, costs);
+    FN(plan_free)(&pl);
+    return c;
+}
+
+/* setConstraintImage(alpha): ARAP/deformation/src/CombinedSolver.h:223-242.  float arithmetic in
+ * the reference regardless of solver precision: computed in float, then widened. */
+static void FN(constraint_image)(int W, int H, const unsigned char *mask_red, const int *cons, int ncons,
+                                 float alpha, REAL *C)
+{
+    size_t N = (size_t)W * H;
+    for (size_t i = 0; i < N; ++i) C[2 * i] = C[2 * i + 1] = (REAL)-1.0f;
+    for (int k = 0; k < ncons; ++k) {
+        int x = cons[4 * k], y = cons[4 * k + 1];
+        if (x < 0 || x >= W || y < 0 || y >= H) continue; /* reference would read out of bounds */
+        if (mask_red[x + (size_t)W * y] == 0) {
+            float nx = (1.0f - alpha) * (float)x + alpha * (float)cons[4 * k + 2];
+            float ny = (1.0f - alpha) * (float)y + alpha * (float)cons[4 * k + 3];
+            C[2 * (x + (size_t)W * y)] = (REAL)nx;
+            C[2 * (x + (size_t)W * y) + 1] = (REAL)ny;
+        }
+    }
+}
+
+/* Full frame schedule of arap_deform:
+ *   border pins        ARAP/deformation/src/main.cpp:130-136 (appended after the file constraints)
+ *   resetGPU           CombinedSolver.h:207-221   U = O = (x,y), A = 0, Mask = (float)red
+ *   weights            CombinedSolver.h:173-177   w_fit = sqrt(100), w_reg = sqrt(0.01)
+ *   ramp + warm start  CombinedSolverBase.h:99-120, CombinedSolver.h:199-201: for i < numIter:
+ *                      setConstraintImage((i+1)/numIter); solve(nIterations, lIterations)
+ *   (numIter == 1 runs a single solve with alpha = 1: CombinedSolverBase.h:101-106)
+ * cons: ncons x 4 ints (x1 y1 x2 y2) from the constraint file (main.cpp:26-50).
+ * O_out[N][2], A_out[N]; final_costs[numIter] (may be NULL) = Opt_ProblemCurrentCost after each solve. */
+void FN(oracle_frame)(int W, int H, const unsigned char *mask_red, const int *cons, int ncons,
+                      int add_border_pins, int numIter, int nIterations, int lIterations, int mode,
+                      int trig, REAL *O_out, REAL *A_out, double *final_costs)
+{
+    size_t N = (size_t)W * H;
+    int nb = add_border_pins ? (2 * (W + H) - 4) : 0;
+    if (add_border_pins && (W < 2 || H < 2)) nb = W * H;
+    int *all = (int *)malloc(sizeof(int) * 4 * (size_t)(ncons + nb + 1));
+    memcpy(all, cons, sizeof(int) * 4 * (size_t)ncons);
+    int nall = ncons;
+    if (add_border_pins)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                if (y == 0 || x == 0 || y == H - 1 || x == W - 1) {
+                    all[4 * nall] = x; all[4 * nall + 1] = y; all[4 * nall + 2] = x; all[4 * nall + 3] = y;
+                    ++nall;
+                }
+    REAL *U = (REAL *)malloc(sizeof(REAL) * 2 * N), *C = (REAL *)malloc(sizeof(REAL) * 2 * N);
+    REAL *M = (REAL *)malloc(sizeof(REAL) * N);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            size_t i = (size_t)(x + W * y);
+            U[2 * i] = O_out[2 * i] = (REAL)(float)x;
+            U[2 * i + 1] = O_out[2 * i + 1] = (REAL)(float)y;
+            A_out[i] = 0;
+            M[i] = (REAL)(float)mask_red[i];
+        }
+    float wfit = sqrtf(100.0f), wreg = sqrtf(0.01f);
+    FN(Prob) pb = {W, H, U, C, M, (REAL)wfit, (REAL)wreg, trig};
+    FN(Plan) pl;
+    FN(plan_alloc)(&pl, N);
+    for (int i = 0; i < numIter; ++i) {
+        float alpha = (float)(i + 1) / (float)numIter;
+        FN(constraint_image)(W, H, mask_red, all, nall, alpha, C);
+        double c = FN(solve_)(&pb, &pl, O_out, A_out, nIterations, lIterations, mode, NULL);
+        if (final_costs) final_costs[i] = c;
+    }
+    FN(plan_free)(&pl);
+    free(U); free(C); free(M); free(all);
+}
+
+/* exported so tests can build Constraints images exactly as the reference host does */
+void FN(oracle_constraint_image)(int W, int H, const unsigned char *mask_red, const int *cons, int ncons,
+                                 float alpha, REAL *C)
+{
+    FN(constraint_image)(W, H, mask_red, cons, ncons, alpha, C);
+}
+
+#undef CAT_
+#undef CAT
+#undef FN
