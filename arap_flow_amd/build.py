@@ -1,0 +1,42 @@
+"""Build libarapopt.so (HIP, gfx950 only) in-tree: arap_flow_amd/lib/libarapopt.so.
+
+hipcc cross-compiles without a GPU.  Flags that matter for results:
+  -ffp-contract=off     every float operator is one IEEE operation (parity tier T3)
+  -munsafe-fp-atomics   float64 atomic add is the hardware global_atomic_add_f64, not a CAS loop
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "arapopt.hip")
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("arapopt.hip", "arap_device.h", "arap_kernels.h", "arap_warp.h")]
+DEPS.append(os.path.join(HERE, "..", "include", "arap_opt.h"))
+OUT_DIR = os.path.join(HERE, "lib")
+OUT = os.path.join(OUT_DIR, "libarapopt.so")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+
+
+def up_to_date():
+    if not os.path.exists(OUT):
+        return False
+    t = os.path.getmtime(OUT)
+    return all(os.path.getmtime(d) <= t for d in DEPS)
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

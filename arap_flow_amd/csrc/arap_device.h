@@ -1,0 +1,151 @@
+// arap_device.h -- per-vertex device math of the ARAP Gauss-Newton / PCG solve for gfx950.
+//
+// The energy is the one of the reference's arap_plan.t:1-23; the three generated functions of the
+// reference (evalJTF o.t:2129-2172, applyJTJ o.t:2029-2089, cost o.t:2375-2385) are written here in
+// closed form (derivation: DESIGN.md "The math").  Everything is float32 (precision.t:1-6) except
+// the reductions, which accumulate float32 per-vertex terms in float64 (DESIGN.md "Reductions").
+//
+// This translation unit is compiled with -ffp-contract=off: each operator below is one IEEE-754
+// operation, in the order written, so a CPU implementation with the same operation list reproduces
+// the results bit for bit (parity tier T3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace arap {
+
+// ---- per-vertex flag byte, rebuilt at every Gauss-Newton step from Mask and Constraints --------
+// bit s (0..3): edge to neighbour s of the stencil {(1,0),(-1,0),(0,1),(0,-1)} (arap_plan.t:14) is
+//               valid: neighbour in bounds, Mask == 0 at both ends (arap_plan.t:17)
+// bit 4       : fitting residual valid: Constraints.x >= 0 and Constraints.y >= 0 (arap_plan.t:22)
+// bit 5       : vertex active, i.e. not excluded: Mask == 0 (arap_plan.t:11)
+enum : unsigned { F_E0 = 1u, F_E1 = 2u, F_E2 = 4u, F_E3 = 8u, F_FIT = 16u, F_ACT = 32u };
+
+constexpr int TILE_X = 64;   // one wavefront = 64 consecutive x of one row: 256-B coalesced rows
+constexpr int TILE_Y = 4;    // 4 wavefronts per workgroup
+constexpr int NSHARD = 32;   // reduction shards per scalar (atomic contention)
+
+// One frame ("slot") of a batch: the five problem images of arap_plan.t:2-6 and the two weights.
+// Lives in device memory; the kernels index it with blockIdx.z.
+struct Slot {
+    float2* O;        // Offset      in/out  [N]
+    float* A;         // Angle       in/out  [N]
+    const float2* U;  // UrShape             [N]
+    const float2* C;  // Constraints         [N]
+    const float* M;   // Mask                [N]
+    float wf, wr;     // w_fitSqrt, w_regSqrt
+    int pad_[2];
+};
+
+// Plan-owned solver state (the GN subset of makePlan, solverGPUGaussNewton.t:1254-1284), one
+// contiguous block per image with stride N per slot.  3-vectors are split like the unknowns:
+// an Offset-shaped float2 image and an Angle-shaped float image.
+struct PlanDev {
+    int W, H, N;
+    int tilesX, tilesY;
+    int nslots;              // reduction slots per frame in `red`
+    Slot* slots;             // [batch]
+    float2 *deltaO, *rO, *zO, *pO0, *pO1, *ApO, *preO, *cs;
+    float *deltaA, *rA, *zA, *pA0, *pA1, *ApA, *preA;
+    uint8_t* flags;          // [batch][N]
+    uint8_t* tileact;        // [batch][tilesX*tilesY]  1 = tile holds an active vertex
+    double* red;             // [batch][nslots][NSHARD]  PCG scalars of the current GN step
+    double* costred;         // [batch][ncost][NSHARD]   cost after Init (index 0) and after each step
+    int ncost;
+};
+
+// ---- cos/sin: same operation list as oracle/arap_oracle.c:arap_sincos_spec ----------------------
+// The reference calls libdevice __nv_cosf/__nv_sinf (util.t:160-174).  Here: Cody-Waite reduction
+// with the fdlibm split of pi/2 and Taylor polynomials, all in IEEE double +,-,*,rint, rounded to
+// float once.  Evaluated once per vertex per Gauss-Newton step, never inside the PCG loop.
+__device__ __forceinline__ float2 sincos_spec(float af)
+{
+    const double a = (double)af;
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;
+    const double pio2_lo = 6.07710050650619224932e-11;
+    const double k = rint(a * two_over_pi);
+    const double r = (a - k * pio2_hi) - k * pio2_lo;
+    const double r2 = r * r;
+    double ps = -1.0 / 1307674368000.0;
+    ps = ps * r2 + 1.0 / 6227020800.0;
+    ps = ps * r2 - 1.0 / 39916800.0;
+    ps = ps * r2 + 1.0 / 362880.0;
+    ps = ps * r2 - 1.0 / 5040.0;
+    ps = ps * r2 + 1.0 / 120.0;
+    ps = ps * r2 - 1.0 / 6.0;
+    const double sr = r + r * (r2 * ps);
+    double pc = 1.0 / 20922789888000.0;
+    pc = pc * r2 - 1.0 / 87178291200.0;
+    pc = pc * r2 + 1.0 / 479001600.0;
+    pc = pc * r2 - 1.0 / 3628800.0;
+    pc = pc * r2 + 1.0 / 40320.0;
+    pc = pc * r2 - 1.0 / 720.0;
+    pc = pc * r2 + 1.0 / 24.0;
+    pc = pc * r2 - 0.5;
+    const double cr = 1.0 + r2 * pc;
+    const int q = (int)((long long)k & 3);
+    double c, s;
+    if (q == 0) { c = cr; s = sr; }
+    else if (q == 1) { c = -sr; s = cr; }
+    else if (q == 2) { c = -cr; s = -sr; }
+    else { c = sr; s = -cr; }
+    return make_float2((float)c, (float)s);
+}
+
+// guardedInvert, CERES variant (solverGPUGaussNewton.t:323-332)
+__device__ __forceinline__ float ginv(float d)
+{
+    const float t = 1.0f + __fsqrt_rn(d);
+    return __fdiv_rn(1.0f, t * t);
+}
+
+__device__ __forceinline__ float dot3(float ax, float ay, float aa, float bx, float by, float ba)
+{
+    return (ax * bx + ay * by) + aa * ba;
+}
+
+// neighbour index offset of stencil entry s
+__device__ __forceinline__ int noff(int s, int W) { return s == 0 ? 1 : (s == 1 ? -1 : (s == 2 ? W : -W)); }
+
+// ---- reductions -------------------------------------------------------------------------------
+// wave64 shuffle tree on doubles, then one value per wavefront combined through LDS, then ONE
+// float64 atomic per workgroup into shard (workgroup index % NSHARD) of the target scalar.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// all threads of the workgroup must call; blockDim = TILE_X*TILE_Y
+__device__ __forceinline__ void block_reduce_atomic(double v, double* target_shards, unsigned wg_linear)
+{
+    __shared__ double wsum[TILE_Y];
+    v = wave_sum(v);
+    const unsigned lane = threadIdx.x, wave = threadIdx.y;   // block = (64, TILE_Y)
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (wave == 0 && lane == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TILE_Y; ++w) t += wsum[w];
+        if (t != 0.0)   // adding an exact zero changes nothing: skip the memory-side atomic
+            __hip_atomic_fetch_add(target_shards + (wg_linear % NSHARD), t, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// sum of the NSHARD shards of one scalar, by every wavefront for itself (lanes >= NSHARD add 0)
+__device__ __forceinline__ float read_scalar(const double* shards)
+{
+    const unsigned lane = threadIdx.x;
+    double v = lane < (unsigned)NSHARD
+                   ? __hip_atomic_load(shards + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                   : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return (float)v;
+}
+
+}  // namespace arap

@@ -1,0 +1,337 @@
+// arap_kernels.h -- HIP kernels of the Gauss-Newton / PCG solve (gfx950, wave64).
+//
+// Kernel map (reference kernels: solverGPUGaussNewton.t:361-592, see DESIGN.md "Kernels"):
+//   k_gn_prep    : per GN step: cos/sin of Angle, flag byte, tile activity        (new; replaces the
+//                  per-iteration re-evaluation of cos/sin, Mask and Constraints of the generated code)
+//   k_gn_init    : PCGInit1 (:361-397)
+//   k_pcg_a      : PCGStep3 of the previous iteration (:537-550) fused with PCGStep1 (:421-434)
+//   k_pcg_b      : PCGStep2 (:446-489)
+//   k_gn_update  : PCGLinearUpdate (:552-557)
+//   k_cost       : computeCost (:580-592)
+// Launch shape: workgroup = 64 x 4 threads (4 wavefronts, each 64 consecutive x of one row),
+// grid = (ceil(W/64), ceil(H/4), batch); one thread per mesh vertex.
+#pragma once
+#include "arap_device.h"
+
+namespace arap {
+
+struct VIdx {
+    int x, y, i, b;       // vertex coords, linear index within the frame, slot
+    size_t g;             // b*N + i : index into the plan-owned [batch][N] images
+    unsigned wg;          // linear workgroup index within the frame
+    bool in;              // inside the image
+};
+
+__device__ __forceinline__ VIdx vidx(const PlanDev& pd)
+{
+    VIdx v;
+    v.x = blockIdx.x * TILE_X + threadIdx.x;
+    v.y = blockIdx.y * TILE_Y + threadIdx.y;
+    v.b = blockIdx.z;
+    v.in = v.x < pd.W && v.y < pd.H;
+    v.i = v.x + pd.W * v.y;
+    v.g = (size_t)v.b * pd.N + (v.in ? v.i : 0);
+    v.wg = blockIdx.y * gridDim.x + blockIdx.x;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
+{
+    const VIdx v = vidx(pd);
+    const Slot sl = pd.slots[v.b];
+    unsigned f = 0;
+    if (v.in) {
+        const int W = pd.W, H = pd.H;
+        const bool act = sl.M[v.i] == 0.0f;
+        if (act) {
+            f = F_ACT;
+            if (v.x + 1 < W && sl.M[v.i + 1] == 0.0f) f |= F_E0;
+            if (v.x > 0 && sl.M[v.i - 1] == 0.0f) f |= F_E1;
+            if (v.y + 1 < H && sl.M[v.i + W] == 0.0f) f |= F_E2;
+            if (v.y > 0 && sl.M[v.i - W] == 0.0f) f |= F_E3;
+            const float2 c = sl.C[v.i];
+            if (c.x >= 0.0f && c.y >= 0.0f) f |= F_FIT;
+        }
+        pd.flags[v.g] = (uint8_t)f;
+        pd.cs[v.g] = sincos_spec(sl.A[v.i]);
+    }
+    const int any = __syncthreads_or((int)(f & F_ACT));
+    if (threadIdx.x == 0 && threadIdx.y == 0)
+        pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCGInit1: delta = 0; (g, D) = evalJTF; r = -g; pre = guardedInvert(D); p = pre*r; rho0 += r.p
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
+{
+    const VIdx v = vidx(pd);
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    const Slot sl = pd.slots[v.b];
+    const unsigned f = v.in ? pd.flags[v.g] : 0u;
+    double d = 0.0;
+    if (f & F_ACT) {
+        const float wr = sl.wr, wf = sl.wf;
+        const size_t gb = (size_t)v.b * pd.N;
+        const float2 csi = pd.cs[v.g];
+        const float ci = csi.x, si = csi.y;
+        const float2 Oi = sl.O[v.i], Ui = sl.U[v.i];
+        float gx = 0.f, gy = 0.f, ga = 0.f, dO = 0.f, dA = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!(f & (1u << s))) continue;
+            const int n = v.i + noff(s, pd.W);
+            const float2 csn = pd.cs[gb + n];
+            const float cn = csn.x, sn = csn.y;
+            const float2 On = sl.O[n], Un = sl.U[n];
+            const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
+            const float ox = Oi.x - On.x, oy = Oi.y - On.y;
+            const float ex = wr * (ox - (ci * dx - si * dy));
+            const float ey = wr * (oy - (si * dx + ci * dy));
+            const float fx = wr * ((cn * dx - sn * dy) - ox);
+            const float fy = wr * ((sn * dx + cn * dy) - oy);
+            const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
+            gx = gx + wr * (ex - fx);
+            gy = gy + wr * (ey - fy);
+            ga = ga - wr * (qx * ex + qy * ey);
+            dO = dO + (wr * wr + wr * wr);
+            dA = dA + (wr * wr) * (qx * qx + qy * qy);
+        }
+        float dOf = dO;
+        if (f & F_FIT) {
+            const float2 Ci = sl.C[v.i];
+            gx = gx + wf * (wf * (Oi.x - Ci.x));
+            gy = gy + wf * (wf * (Oi.y - Ci.y));
+            dOf = dO + wf * wf;
+        }
+        const float rx = -gx, ry = -gy, ra = -ga;
+        const float mo = ginv(dOf), ma = ginv(dA);
+        const float px = mo * rx, py = mo * ry, pa = ma * ra;
+        pd.deltaO[v.g] = make_float2(0.f, 0.f);
+        pd.deltaA[v.g] = 0.f;
+        pd.rO[v.g] = make_float2(rx, ry);
+        pd.rA[v.g] = ra;
+        pd.preO[v.g] = make_float2(mo, mo);
+        pd.preA[v.g] = ma;
+        pd.pO0[v.g] = make_float2(px, py);
+        pd.pA0[v.g] = pa;
+        d = (double)dot3(rx, ry, ra, px, py, pa);
+    } else if (v.in) {
+        pd.preO[v.g] = make_float2(0.f, 0.f);   // PCGInit1 stores pre = 0 on excluded vertices (:395)
+        pd.preA[v.g] = 0.f;
+    }
+    block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + 0) * NSHARD, v.wg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Iteration l, phase A.  p_l = (l == 0) ? p_init : z + beta * p_{l-1}, with
+// beta = rho_l / rho_{l-1} if rho_{l-1} > 0 else 0 (PCGStep3).  Then Ap = J^T J p_l and
+// sigma_l += p_l . Ap (PCGStep1).  p is double-buffered (read `pin`, write `pout`) because the
+// stencil needs the neighbours' p_l, which this kernel recomputes from their z and p_{l-1}.
+// reduction slots of the GN step: 0 = rho_0 ; 2l+1 = sigma_l ; 2l+2 = rho_{l+1}
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
+{
+    const VIdx v = vidx(pd);
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    const Slot sl = pd.slots[v.b];
+    const size_t gb = (size_t)v.b * pd.N;
+    const float2* __restrict__ pinO = (l & 1) ? pd.pO1 : pd.pO0;
+    const float* __restrict__ pinA = (l & 1) ? pd.pA1 : pd.pA0;
+    float2* __restrict__ poutO = (l & 1) ? pd.pO0 : pd.pO1;
+    float* __restrict__ poutA = (l & 1) ? pd.pA0 : pd.pA1;
+    float beta = 0.f;
+    if (l > 0) {
+        const double* rs = pd.red + (size_t)v.b * pd.nslots * NSHARD;
+        const float rhoNew = read_scalar(rs + (size_t)(2 * l) * NSHARD);
+        const float rhoOld = read_scalar(rs + (size_t)(2 * l - 2) * NSHARD);
+        if (rhoOld > 0.f) beta = __fdiv_rn(rhoNew, rhoOld);
+    }
+    const unsigned f = v.in ? pd.flags[v.g] : 0u;
+    double d = 0.0;
+    if (f & F_ACT) {
+        const float wr2 = sl.wr * sl.wr;
+        float2 pO = pinO[v.g];
+        float pA = pinA[v.g];
+        if (l > 0) {
+            const float2 zO = pd.zO[v.g];
+            const float zA = pd.zA[v.g];
+            pO.x = zO.x + beta * pO.x;
+            pO.y = zO.y + beta * pO.y;
+            pA = zA + beta * pA;
+        }
+        poutO[v.g] = pO;
+        poutA[v.g] = pA;
+        const float2 csi = pd.cs[v.g];
+        const float ci = csi.x, si = csi.y;
+        const float2 Ui = sl.U[v.i];
+        float ax = 0.f, ay = 0.f, aa = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!(f & (1u << s))) continue;
+            const int n = v.i + noff(s, pd.W);
+            float2 qO = pinO[gb + n];
+            float qA = pinA[gb + n];
+            if (l > 0) {
+                const float2 zO = pd.zO[gb + n];
+                const float zA = pd.zA[gb + n];
+                qO.x = zO.x + beta * qO.x;
+                qO.y = zO.y + beta * qO.y;
+                qA = zA + beta * qA;
+            }
+            const float2 csn = pd.cs[gb + n];
+            const float cn = csn.x, sn = csn.y;
+            const float2 Un = sl.U[n];
+            const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
+            const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
+            const float hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;
+            const float px = pO.x - qO.x, py = pO.y - qO.y;
+            const float tx = px - qx * pA, ty = py - qy * pA;
+            ax = ax + wr2 * ((px + tx) - hx * qA);
+            ay = ay + wr2 * ((py + ty) - hy * qA);
+            aa = aa - wr2 * (qx * tx + qy * ty);
+        }
+        if (f & F_FIT) {
+            const float wf2 = sl.wf * sl.wf;
+            ax = ax + wf2 * pO.x;
+            ay = ay + wf2 * pO.y;
+        }
+        pd.ApO[v.g] = make_float2(ax, ay);
+        pd.ApA[v.g] = aa;
+        d = (double)dot3(pO.x, pO.y, pA, ax, ay, aa);
+    }
+    block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 1)) * NSHARD, v.wg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Iteration l, phase B = PCGStep2: alpha = rho_l / sigma_l if sigma_l > 0 else 0;
+// delta += alpha p ; r -= alpha Ap ; z = pre * r ; rho_{l+1} += z.r
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
+{
+    const VIdx v = vidx(pd);
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    const float2* __restrict__ pO_ = (l & 1) ? pd.pO0 : pd.pO1;   // written by k_pcg_a(l)
+    const float* __restrict__ pA_ = (l & 1) ? pd.pA0 : pd.pA1;
+    const double* rs = pd.red + (size_t)v.b * pd.nslots * NSHARD;
+    const float rho = read_scalar(rs + (size_t)(2 * l) * NSHARD);
+    const float sigma = read_scalar(rs + (size_t)(2 * l + 1) * NSHARD);
+    float alpha = 0.f;
+    if (sigma > 0.f) alpha = __fdiv_rn(rho, sigma);
+    const unsigned f = v.in ? pd.flags[v.g] : 0u;
+    double d = 0.0;
+    if (f & F_ACT) {
+        const float2 pO = pO_[v.g], ApO = pd.ApO[v.g], mO = pd.preO[v.g];
+        const float pA = pA_[v.g], ApA = pd.ApA[v.g], mA = pd.preA[v.g];
+        float2 dO = pd.deltaO[v.g], rO = pd.rO[v.g];
+        float dA = pd.deltaA[v.g], rA = pd.rA[v.g];
+        dO.x = dO.x + alpha * pO.x;
+        dO.y = dO.y + alpha * pO.y;
+        dA = dA + alpha * pA;
+        rO.x = rO.x - alpha * ApO.x;
+        rO.y = rO.y - alpha * ApO.y;
+        rA = rA - alpha * ApA;
+        const float zx = mO.x * rO.x, zy = mO.y * rO.y, za = mA * rA;
+        pd.deltaO[v.g] = dO;
+        pd.deltaA[v.g] = dA;
+        pd.rO[v.g] = rO;
+        pd.rA[v.g] = rA;
+        pd.zO[v.g] = make_float2(zx, zy);
+        pd.zA[v.g] = za;
+        d = (double)dot3(zx, zy, za, rO.x, rO.y, rA);
+    }
+    block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD, v.wg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCGLinearUpdate: X += delta on non-excluded vertices
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd)
+{
+    const VIdx v = vidx(pd);
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    if (!v.in || !(pd.flags[v.g] & F_ACT)) return;
+    const Slot sl = pd.slots[v.b];
+    const float2 d = pd.deltaO[v.g];
+    float2 o = sl.O[v.i];
+    o.x = o.x + d.x;
+    o.y = o.y + d.y;
+    sl.O[v.i] = o;
+    sl.A[v.i] = sl.A[v.i] + pd.deltaA[v.g];
+}
+
+// ------------------------------------------------------------------------------------------------
+// computeCost: 0.5 * sum of squared residuals centred on each non-excluded vertex.  Self contained
+// (reads Mask / Constraints / Angle directly) because it also runs at Init, before any k_gn_prep.
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_cost(PlanDev pd, int cost_index)
+{
+    const VIdx v = vidx(pd);
+    const Slot sl = pd.slots[v.b];
+    double d = 0.0;
+    if (v.in && sl.M[v.i] == 0.0f) {
+        const int W = pd.W, H = pd.H;
+        const float wr = sl.wr, wf = sl.wf;
+        const float2 cs = sincos_spec(sl.A[v.i]);
+        const float2 Oi = sl.O[v.i], Ui = sl.U[v.i];
+        float t = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int nx = v.x + (s == 0 ? 1 : (s == 1 ? -1 : 0));
+            const int ny = v.y + (s == 2 ? 1 : (s == 3 ? -1 : 0));
+            if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+            const int n = nx + W * ny;
+            if (sl.M[n] != 0.0f) continue;
+            const float2 On = sl.O[n], Un = sl.U[n];
+            const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
+            const float ex = wr * ((Oi.x - On.x) - (cs.x * dx - cs.y * dy));
+            const float ey = wr * ((Oi.y - On.y) - (cs.y * dx + cs.x * dy));
+            t = t + ex * ex;
+            t = t + ey * ey;
+        }
+        const float2 Ci = sl.C[v.i];
+        if (Ci.x >= 0.0f && Ci.y >= 0.0f) {
+            const float fx = wf * (Oi.x - Ci.x), fy = wf * (Oi.y - Ci.y);
+            t = t + fx * fx;
+            t = t + fy * fy;
+        }
+        d = (double)(0.5f * t);
+    }
+    block_reduce_atomic(d, pd.costred + ((size_t)v.b * pd.ncost + cost_index) * NSHARD, v.wg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel-level test entry points (ArapFlow_EvalJTF / ArapFlow_ApplyJTJ): raw gradient, diagonal and
+// operator on caller images, using the same device code as the solver kernels above through a
+// temporary plan (see arap_solver.hip).
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_export_jtf(PlanDev pd, float2* gO, float* gA, float2* dO,
+                                                                float* dA)
+{
+    // after k_gn_prep + k_gn_init on slot 0: g = -r ; D recovered from pre is lossy, so recompute D
+    const VIdx v = vidx(pd);
+    if (!v.in) return;
+    const Slot sl = pd.slots[0];
+    const unsigned f = pd.flags[v.g];
+    float2 go = make_float2(0.f, 0.f), d_o = make_float2(0.f, 0.f);
+    float ga = 0.f, d_a = 0.f;
+    if (f & F_ACT) {
+        const float2 r = pd.rO[v.g];
+        go = make_float2(-r.x, -r.y);
+        ga = -pd.rA[v.g];
+        const float wr = sl.wr, wf = sl.wf;
+        const float2 csi = pd.cs[v.g];
+        const float2 Ui = sl.U[v.i];
+        float DO = 0.f, DA = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!(f & (1u << s))) continue;
+            const float2 Un = sl.U[v.i + noff(s, pd.W)];
+            const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
+            const float qx = -csi.y * dx - csi.x * dy, qy = csi.x * dx - csi.y * dy;
+            DO = DO + (wr * wr + wr * wr);
+            DA = DA + (wr * wr) * (qx * qx + qy * qy);
+        }
+        if (f & F_FIT) DO = DO + wf * wf;
+        d_o = make_float2(DO, DO);
+        d_a = DA;
+    }
+    gO[v.i] = go; gA[v.i] = ga; dO[v.i] = d_o; dA[v.i] = d_a;
+}
+
+}  // namespace arap

@@ -1,0 +1,850 @@
+// arapopt.hip -- libarapopt.so: host side of the MI355X-native ARAP solver + the C ABI of
+// include/arap_opt.h.  Built for gfx950 only (see arap_flow_amd/build.py).
+//
+// Host-side structure mirrors the reference's plan lifecycle:
+//   Opt_NewState/ProblemDefine/ProblemPlan   createwrapper.t:124-220, o.t:2521-2558
+//   init / step / cost / setSolverParameter  solverGPUGaussNewton.t:956-1007, 1016-1177, 1179-1221
+// but one Gauss-Newton step is a single hipGraph launch (2 + 2*lIterations + 1 kernel nodes and one
+// memset node) with every PCG scalar kept in device memory: no per-iteration memset/memcpy calls,
+// no host round trip inside a solve (the reference issues ~4 tiny API calls per PCG iteration,
+// solverGPUGaussNewton.t:1058-1091, and a blocking read-back per step, :790-797).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/arap_opt.h"
+#include "arap_kernels.h"
+#include "arap_warp.h"
+
+using namespace arap;
+
+#define ARAPOPT_VERSION "arapopt 0.1.0 gfx950"
+
+// Device API failure -> message + exit, as the reference does (solverGPUGaussNewton.t:59-73).
+static void hip_fatal(hipError_t e, const char* what, const char* file, int line)
+{
+    fprintf(stderr, "arapopt: HIP error %d (%s) in %s at %s:%d\n", (int)e, hipGetErrorString(e), what, file, line);
+    exit((int)e ? (int)e : 1);
+}
+#define HC(call)                                                     \
+    do {                                                             \
+        hipError_t e_ = (call);                                      \
+        if (e_ != hipSuccess) hip_fatal(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+struct KernelTimer {            // collectPerKernelTimingInfo (Opt.h:23-25, util.t:414-511)
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    void clear()
+    {
+        for (auto& r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        recs.clear();
+    }
+    void report()
+    {
+        std::map<std::string, std::pair<int, double>> agg;
+        for (auto& r : recs) {
+            float ms = 0.f;
+            (void)hipEventSynchronize(r.b);
+            (void)hipEventElapsedTime(&ms, r.a, r.b);
+            agg[r.name].first++;
+            agg[r.name].second += ms;
+        }
+        printf("--------------------------------------------------------\n");
+        printf("        Kernel        |   Count  |   Total   | Average \n");
+        printf("----------------------+----------+-----------+----------\n");
+        for (auto& kv : agg)
+            printf(" %-20s |   %4d   | %8.3fms| %7.4fms\n", kv.first.c_str(), kv.second.first,
+                   kv.second.second, kv.second.second / kv.second.first);
+        printf("--------------------------------------------------------\n");
+        clear();
+    }
+};
+
+struct Opt_State {
+    int verbosity = 0;
+    int timing = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;     // where all work is enqueued (NULL = null stream)
+    hipStream_t cap = nullptr;        // private stream used only for graph capture
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    KernelTimer ktimer;
+    bool use_graph = true;
+};
+
+struct Opt_Problem {
+    int kind;    // 0 = gaussNewtonGPU
+};
+
+// solver parameter table and defaults: solverGPUGaussNewton.t:26-39, :148-163
+struct SolverParameters {
+    int residual_reset_period = 10;
+    float min_relative_decrease = 1e-3f, min_trust_region_radius = 1e-32f, max_trust_region_radius = 1e16f,
+          q_tolerance = 1e-4f, function_tolerance = 1e-6f, trust_region_radius = 1e4f,
+          radius_decrease_factor = 2.0f, min_lm_diagonal = 1e-6f, max_lm_diagonal = 1e32f;
+    int nIterations = 10, lIterations = 10;
+    int nIter = 0;
+};
+
+struct Opt_Plan {
+    Opt_State* st = nullptr;
+    int W = 0, H = 0, N = 0, batch = 1;
+    PlanDev pd{};
+    SolverParameters sp;
+    std::vector<Slot> hslots;       // host mirror of pd.slots
+    std::vector<Slot> uploaded;
+    void* block = nullptr;          // all plan-owned images
+    int lcap = 0;                   // lIterations capacity of pd.red
+    int ccap = 0;                   // cost entries capacity of pd.costred
+    int nb = 1;                     // slots active in the current solve (grid.z)
+    // graph of one GN step, keyed by (lIterations, nb)
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
+    int g_l = -1, g_nb = -1;
+    double prevCost[1] = {0.0};
+    bool cost_valid = false;
+    int cost_index = 0;
+
+    dim3 grid() const { return dim3(pd.tilesX, pd.tilesY, nb); }
+    dim3 blk() const { return dim3(TILE_X, TILE_Y, 1); }
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
+{
+    HC(hipSetDevice(st->device));
+    Opt_Plan* p = new Opt_Plan();
+    p->st = st;
+    p->W = W; p->H = H; p->N = W * H; p->batch = batch;
+    PlanDev& pd = p->pd;
+    pd.W = W; pd.H = H; pd.N = p->N;
+    pd.tilesX = (W + TILE_X - 1) / TILE_X;
+    pd.tilesY = (H + TILE_Y - 1) / TILE_Y;
+    const size_t BN = (size_t)batch * p->N;
+    // 8 float2 images + 7 float images + flags + tileact + slots, zero initialised (o.t:627-632)
+    const size_t sz2 = align_up(BN * sizeof(float2), 256), sz1 = align_up(BN * sizeof(float), 256);
+    const size_t szf = align_up(BN, 256), szt = align_up((size_t)batch * pd.tilesX * pd.tilesY, 256);
+    const size_t szs = align_up(sizeof(Slot) * batch, 256);
+    const size_t total = 8 * sz2 + 7 * sz1 + szf + szt + szs;
+    HC(hipMalloc(&p->block, total));
+    HC(hipMemsetAsync(p->block, 0, total, st->stream));
+    char* c = (char*)p->block;
+    auto take = [&](size_t s) { char* r = c; c += s; return r; };
+    pd.deltaO = (float2*)take(sz2); pd.rO = (float2*)take(sz2); pd.zO = (float2*)take(sz2);
+    pd.pO0 = (float2*)take(sz2); pd.pO1 = (float2*)take(sz2); pd.ApO = (float2*)take(sz2);
+    pd.preO = (float2*)take(sz2); pd.cs = (float2*)take(sz2);
+    pd.deltaA = (float*)take(sz1); pd.rA = (float*)take(sz1); pd.zA = (float*)take(sz1);
+    pd.pA0 = (float*)take(sz1); pd.pA1 = (float*)take(sz1); pd.ApA = (float*)take(sz1);
+    pd.preA = (float*)take(sz1);
+    pd.flags = (uint8_t*)take(szf);
+    pd.tileact = (uint8_t*)take(szt);
+    pd.slots = (Slot*)take(szs);
+    pd.red = nullptr; pd.costred = nullptr; pd.nslots = 0; pd.ncost = 0;
+    p->hslots.assign(batch, Slot{});
+    return p;
+}
+
+static void plan_drop_graph(Opt_Plan* p)
+{
+    if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+    p->g_l = p->g_nb = -1;
+}
+
+static void plan_free(Opt_Plan* p)
+{
+    if (!p) return;
+    HC(hipStreamSynchronize(p->st->stream));
+    plan_drop_graph(p);
+    if (p->pd.red) (void)hipFree(p->pd.red);
+    if (p->pd.costred) (void)hipFree(p->pd.costred);
+    if (p->block) (void)hipFree(p->block);
+    delete p;
+}
+
+// make sure the scalar arrays can hold lIterations PCG iterations / ncost cost entries
+static void plan_reserve(Opt_Plan* p, int lIterations, int ncost)
+{
+    Opt_State* st = p->st;
+    if (lIterations > p->lcap || !p->pd.red) {
+        HC(hipStreamSynchronize(st->stream));
+        plan_drop_graph(p);
+        if (p->pd.red) HC(hipFree(p->pd.red));
+        p->lcap = lIterations < 16 ? 16 : lIterations;
+        p->pd.nslots = 2 * p->lcap + 1;
+        HC(hipMalloc(&p->pd.red, (size_t)p->batch * p->pd.nslots * NSHARD * sizeof(double)));
+    }
+    if (ncost > p->ccap || !p->pd.costred) {
+        HC(hipStreamSynchronize(st->stream));
+        plan_drop_graph(p);
+        if (p->pd.costred) HC(hipFree(p->pd.costred));
+        p->ccap = ncost < 16 ? 16 : ncost;
+        p->pd.ncost = p->ccap;
+        HC(hipMalloc(&p->pd.costred, (size_t)p->batch * p->pd.ncost * NSHARD * sizeof(double)));
+    }
+}
+
+static void plan_upload_slots(Opt_Plan* p)
+{
+    if (p->uploaded.size() == p->hslots.size() &&
+        memcmp(p->uploaded.data(), p->hslots.data(), sizeof(Slot) * p->hslots.size()) == 0)
+        return;
+    // pageable source: the copy is staged before the call returns
+    HC(hipMemcpyAsync(p->pd.slots, p->hslots.data(), sizeof(Slot) * p->hslots.size(), hipMemcpyHostToDevice,
+                      p->st->stream));
+    p->uploaded = p->hslots;
+}
+
+#define LAUNCH(p, st_, kname_, kern, grid, blk, ...)                                          \
+    do {                                                                                    \
+        if ((p)->st->timing) {                                                              \
+            KernelTimer::Rec r_;                                                            \
+            r_.name = kname_;                                                               \
+            HC(hipEventCreate(&r_.a)); HC(hipEventCreate(&r_.b));                           \
+            HC(hipEventRecord(r_.a, st_));                                                  \
+            hipLaunchKernelGGL(kern, grid, blk, 0, st_, __VA_ARGS__);                       \
+            HC(hipEventRecord(r_.b, st_));                                                  \
+            (p)->st->ktimer.recs.push_back(r_);                                             \
+        } else {                                                                            \
+            hipLaunchKernelGGL(kern, grid, blk, 0, st_, __VA_ARGS__);                       \
+        }                                                                                   \
+    } while (0)
+
+// enqueue the kernels of one Gauss-Newton step (without the cost) on stream s
+static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
+{
+    const int L = p->sp.lIterations;
+    const dim3 g = p->grid(), b = p->blk();
+    // reduction slots 0 .. 2L of every active frame (contiguous because slot stride is nslots)
+    HC(hipMemsetAsync(p->pd.red, 0, (size_t)p->nb * p->pd.nslots * NSHARD * sizeof(double), s));
+    LAUNCH(p, s, "GNPrep", k_gn_prep, g, b, p->pd);
+    LAUNCH(p, s, "PCGInit1", k_gn_init, g, b, p->pd);
+    for (int l = 0; l < L; ++l) {
+        LAUNCH(p, s, "PCGStepA", k_pcg_a, g, b, p->pd, l);
+        LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
+    }
+    LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, g, b, p->pd);
+}
+
+static void plan_gn_step(Opt_Plan* p)
+{
+    Opt_State* st = p->st;
+    const bool graph_ok = st->use_graph && !st->timing;
+    if (!graph_ok) {
+        enqueue_gn_step(p, st->stream);
+        return;
+    }
+    if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb) {
+        plan_drop_graph(p);
+        HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
+        enqueue_gn_step(p, st->cap);
+        HC(hipStreamEndCapture(st->cap, &p->graph));
+        HC(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
+        p->g_l = p->sp.lIterations;
+        p->g_nb = p->nb;
+    }
+    HC(hipGraphLaunch(p->gexec, st->stream));
+}
+
+static void plan_cost(Opt_Plan* p, int index)
+{
+    LAUNCH(p, p->st->stream, "computeCost", k_cost, p->grid(), p->blk(), p->pd, index);
+    p->cost_index = index;
+    p->cost_valid = false;
+}
+
+// blocking read of the cost entry `index` of slot b (sum of its shards, rounded to float as the
+// reference's device float, solverGPUGaussNewton.t:790-797)
+static double plan_read_cost(Opt_Plan* p, int b, int index)
+{
+    double sh[NSHARD];
+    HC(hipMemcpyAsync(sh, p->pd.costred + ((size_t)b * p->pd.ncost + index) * NSHARD, sizeof(sh),
+                      hipMemcpyDeviceToHost, p->st->stream));
+    HC(hipStreamSynchronize(p->st->stream));
+    double t = 0.0;
+    for (int i = 0; i < NSHARD; ++i) t += sh[i];
+    return (double)(float)t;
+}
+
+static void slot_from_params(Slot& s, void** pp)
+{
+    // plan-declared indices: arap_plan.t:2-8 ; scalars are HOST pointers (util.t:664-692)
+    s.O = (float2*)pp[0];
+    s.A = (float*)pp[1];
+    s.U = (const float2*)pp[2];
+    s.C = (const float2*)pp[3];
+    s.M = (const float*)pp[4];
+    s.wf = *(const float*)pp[5];
+    s.wr = *(const float*)pp[6];
+}
+
+// init: solverGPUGaussNewton.t:956-1007
+static void plan_init(Opt_Plan* p)
+{
+    HC(hipSetDevice(p->st->device));
+    p->sp.nIter = 0;
+    plan_reserve(p, p->sp.lIterations, p->sp.nIterations + 1);
+    plan_upload_slots(p);
+    HC(hipMemsetAsync(p->pd.costred, 0, (size_t)p->nb * p->pd.ncost * NSHARD * sizeof(double), p->st->stream));
+    plan_cost(p, 0);
+}
+
+// step: solverGPUGaussNewton.t:1016-1177 (GN branch)
+static int plan_step(Opt_Plan* p)
+{
+    if (p->sp.nIter < p->sp.nIterations) {
+        plan_upload_slots(p);
+        plan_gn_step(p);
+        plan_cost(p, p->sp.nIter + 1);
+        if (p->st->verbosity > 0) {
+            const double a = plan_read_cost(p, 0, p->sp.nIter), b = plan_read_cost(p, 0, p->sp.nIter + 1);
+            printf("cost: %f -> %f\n", a, b);
+        }
+        p->sp.nIter += 1;
+        return 1;
+    }
+    if (p->st->timing && p->st->verbosity > 0) p->st->ktimer.report();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Problem specification check.  The library hard-codes the energy of arap_plan.t:1-23; the file
+// named in Opt_ProblemDefine is checked declaration by declaration against it.
+// ---------------------------------------------------------------------------------------------
+static std::string strip_spec(const std::string& src)
+{
+    std::string out;
+    size_t i = 0;
+    while (i < src.size()) {
+        if (src[i] == '-' && i + 1 < src.size() && src[i + 1] == '-') {   // Lua comment
+            while (i < src.size() && src[i] != '\n') ++i;
+            continue;
+        }
+        if (!isspace((unsigned char)src[i])) out.push_back(src[i]);
+        ++i;
+    }
+    return out;
+}
+
+static bool spec_is_arap(const std::string& stripped, std::string& why)
+{
+    // every structural element of the energy must be present, in this order of appearance
+    static const char* need[] = {
+        "Dim(\"W\",0)", "Dim(\"H\",1)",
+        "Unknown(\"Offset\",opt_float2,{W,H},0)",
+        "Unknown(\"Angle\",opt_float,{W,H},1)",
+        "Array(\"UrShape\",opt_float2,{W,H},2)",
+        "Array(\"Constraints\",opt_float2,{W,H},3)",
+        "Array(\"Mask\",opt_float,{W,H},4)",
+        "Param(\"w_fitSqrt\",float,5)",
+        "Param(\"w_regSqrt\",float,6)",
+        "UsePreconditioner(true)",
+        "Exclude(Not(eq(Mask(0,0),0)))",
+        "Stencil{{1,0},{-1,0},{0,1},{0,-1}}",
+        "w_regSqrt*((Offset(0,0)-Offset(x,y))-Rotate2D(Angle(0,0),(UrShape(0,0)-UrShape(x,y))))",
+        "InBounds(x,y)*eq(Mask(x,y),0)*eq(Mask(0,0),0)",
+        "Energy(Select(valid,e_reg,0))",
+        "(Offset(0,0)-Constraints(0,0))",
+        "All(greatereq(Constraints(0,0),0))",
+        "Energy(w_fitSqrt*Select(valid,e_fit,0.0))",
+    };
+    size_t pos = 0;
+    for (const char* n : need) {
+        size_t f = stripped.find(n, pos);
+        if (f == std::string::npos) { why = std::string("missing or out of order: ") + n; return false; }
+        pos = f + strlen(n);
+    }
+    // and nothing else that adds energy terms or unknowns
+    size_t cnt = 0, at = 0;
+    while ((at = stripped.find("Energy(", at)) != std::string::npos) { ++cnt; at += 7; }
+    if (cnt != 2) { why = "expected exactly two Energy() terms"; return false; }
+    cnt = 0; at = 0;
+    while ((at = stripped.find("Unknown(", at)) != std::string::npos) { ++cnt; at += 8; }
+    if (cnt != 2) { why = "expected exactly two Unknown() declarations"; return false; }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI, part 1
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+Opt_State* Opt_NewState(Opt_InitializationParameters params)
+{
+    if (params.doublePrecision) {
+        fprintf(stderr, "arapopt: doublePrecision is not supported (float32 only, as the application uses)\n");
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "arapopt: no HIP device available; this library has no CPU fallback\n");
+        return nullptr;
+    }
+    Opt_State* st = new Opt_State();
+    st->verbosity = params.verbosityLevel;
+    st->timing = params.collectPerKernelTimingInfo;
+    HC(hipGetDevice(&st->device));
+    HC(hipStreamCreateWithFlags(&st->cap, hipStreamNonBlocking));
+    HC(hipEventCreate(&st->t0));
+    HC(hipEventCreate(&st->t1));
+    const char* ng = getenv("ARAPOPT_NO_GRAPH");
+    st->use_graph = !(ng && ng[0] == '1');
+    return st;
+}
+
+void ArapFlow_FreeState(Opt_State* st)
+{
+    if (!st) return;
+    (void)hipStreamDestroy(st->cap);
+    (void)hipEventDestroy(st->t0);
+    (void)hipEventDestroy(st->t1);
+    st->ktimer.clear();
+    delete st;
+}
+
+Opt_Problem* Opt_ProblemDefine(Opt_State* state, const char* filename, const char* solverkind)
+{
+    if (!state || !filename || !solverkind) return nullptr;
+    if (strcmp(solverkind, "gaussNewtonGPU") != 0) {
+        if (strcmp(solverkind, "LMGPU") == 0)
+            fprintf(stderr, "arapopt: solver kind LMGPU is not implemented (only gaussNewtonGPU)\n");
+        else
+            fprintf(stderr, "arapopt: unknown solver kind '%s' (expected gaussNewtonGPU)\n", solverkind);
+        return nullptr;
+    }
+    if (strcmp(filename, "builtin:arap") != 0) {
+        FILE* f = fopen(filename, "rb");
+        if (!f) {
+            fprintf(stderr, "arapopt: cannot open problem specification '%s'\n", filename);
+            return nullptr;
+        }
+        std::string src;
+        char buf[4096];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) src.append(buf, n);
+        fclose(f);
+        std::string why;
+        if (!spec_is_arap(strip_spec(src), why)) {
+            fprintf(stderr,
+                    "arapopt: '%s' is not the ARAP image-warping energy this library implements (%s)\n",
+                    filename, why.c_str());
+            return nullptr;
+        }
+    }
+    Opt_Problem* pr = new Opt_Problem();
+    pr->kind = 0;
+    if (state->verbosity > 1) printf("arapopt: problem '%s' (%s) accepted\n", filename, solverkind);
+    return pr;
+}
+
+void Opt_ProblemDelete(Opt_State*, Opt_Problem* problem) { delete problem; }
+
+Opt_Plan* Opt_ProblemPlan(Opt_State* state, Opt_Problem* problem, unsigned int* dimensions)
+{
+    if (!state || !problem || !dimensions) return nullptr;
+    const unsigned W = dimensions[0], H = dimensions[1];
+    if (W == 0 || H == 0 || (uint64_t)W * H > (1ull << 30)) {
+        fprintf(stderr, "arapopt: bad dimensions %u x %u\n", W, H);
+        return nullptr;
+    }
+    return plan_create(state, (int)W, (int)H, 1);
+}
+
+void Opt_PlanFree(Opt_State*, Opt_Plan* plan) { plan_free(plan); }
+
+void Opt_SetSolverParameter(Opt_State*, Opt_Plan* plan, const char* name, void* value)
+{
+    if (!plan || !name || !value) return;
+    SolverParameters& sp = plan->sp;
+#define SETI(f) if (strcmp(name, #f) == 0) { sp.f = *(int*)value; return; }
+#define SETF(f) if (strcmp(name, #f) == 0) { sp.f = *(float*)value; return; }
+    SETI(nIterations) SETI(lIterations) SETI(residual_reset_period)
+    SETF(min_relative_decrease) SETF(min_trust_region_radius) SETF(max_trust_region_radius)
+    SETF(q_tolerance) SETF(function_tolerance) SETF(trust_region_radius) SETF(radius_decrease_factor)
+    SETF(min_lm_diagonal) SETF(max_lm_diagonal)
+#undef SETI
+#undef SETF
+    if (plan->st->verbosity > 0) printf("Warning: tried to set nonexistent solver parameter %s\n", name);
+}
+
+void Opt_ProblemInit(Opt_State*, Opt_Plan* plan, void** problemparams)
+{
+    plan->nb = 1;
+    slot_from_params(plan->hslots[0], problemparams);
+    plan_init(plan);
+}
+
+int Opt_ProblemStep(Opt_State*, Opt_Plan* plan, void** problemparams)
+{
+    slot_from_params(plan->hslots[0], problemparams);
+    return plan_step(plan);
+}
+
+void Opt_ProblemSolve(Opt_State* state, Opt_Plan* plan, void** problemparams)
+{
+    Opt_ProblemInit(state, plan, problemparams);
+    while (Opt_ProblemStep(state, plan, problemparams) != 0) {}
+}
+
+double Opt_ProblemCurrentCost(Opt_State*, Opt_Plan* plan)
+{
+    return plan_read_cost(plan, 0, plan->sp.nIter);
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI, part 2
+// ---------------------------------------------------------------------------------------------
+const char* ArapFlow_Version(void) { return ARAPOPT_VERSION; }
+
+void ArapFlow_SetKernelTiming(Opt_State* state, int on)
+{
+    HC(hipStreamSynchronize(state->stream));
+    state->ktimer.clear();
+    state->timing = on ? 1 : 0;
+}
+
+int ArapFlow_KernelTime(Opt_State* state, const char* kernel_name, double* total_ms, uint64_t* launches)
+{
+    double tot = 0.0;
+    uint64_t n = 0;
+    for (auto& r : state->ktimer.recs) {
+        if (r.name != kernel_name) continue;
+        float ms = 0.f;
+        HC(hipEventSynchronize(r.b));
+        HC(hipEventElapsedTime(&ms, r.a, r.b));
+        tot += ms;
+        ++n;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return n ? 0 : -1;
+}
+
+void ArapFlow_SetStream(Opt_State* state, void* hip_stream) { state->stream = (hipStream_t)hip_stream; }
+
+void ArapFlow_TimerBegin(Opt_State* state) { HC(hipEventRecord(state->t0, state->stream)); }
+
+float ArapFlow_TimerEnd(Opt_State* state)
+{
+    float ms = 0.f;
+    HC(hipEventRecord(state->t1, state->stream));
+    HC(hipEventSynchronize(state->t1));
+    HC(hipEventElapsedTime(&ms, state->t0, state->t1));
+    return ms;
+}
+
+static Opt_Plan* temp_plan(Opt_State* st, unsigned W, unsigned H, const void* O, const void* A, const void* U,
+                           const void* C, const void* M, float wf, float wr)
+{
+    Opt_Plan* p = plan_create(st, (int)W, (int)H, 1);
+    Slot& s = p->hslots[0];
+    s.O = (float2*)O; s.A = (float*)A; s.U = (const float2*)U; s.C = (const float2*)C; s.M = (const float*)M;
+    s.wf = wf; s.wr = wr;
+    p->nb = 1;
+    plan_reserve(p, 1, 1);
+    plan_upload_slots(p);
+    HC(hipMemsetAsync(p->pd.red, 0, (size_t)p->pd.nslots * NSHARD * sizeof(double), st->stream));
+    HC(hipMemsetAsync(p->pd.costred, 0, (size_t)p->pd.ncost * NSHARD * sizeof(double), st->stream));
+    return p;
+}
+
+int ArapFlow_EvalJTF(Opt_State* st, unsigned W, unsigned H, const void* O, const void* A, const void* U,
+                     const void* C, const void* M, float wf, float wr, void* gO, void* gA, void* dO, void* dA)
+{
+    Opt_Plan* p = temp_plan(st, W, H, O, A, U, C, M, wf, wr);
+    hipLaunchKernelGGL(k_gn_prep, p->grid(), p->blk(), 0, st->stream, p->pd);
+    hipLaunchKernelGGL(k_gn_init, p->grid(), p->blk(), 0, st->stream, p->pd);
+    hipLaunchKernelGGL(k_export_jtf, p->grid(), p->blk(), 0, st->stream, p->pd, (float2*)gO, (float*)gA,
+                       (float2*)dO, (float*)dA);
+    hipError_t e = hipStreamSynchronize(st->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    plan_free(p);
+    return (int)e;
+}
+
+int ArapFlow_ApplyJTJ(Opt_State* st, unsigned W, unsigned H, const void* A, const void* U, const void* C,
+                      const void* M, float wf, float wr, const void* pO, const void* pA, void* outO, void* outA)
+{
+    Opt_Plan* p = temp_plan(st, W, H, nullptr, A, U, C, M, wf, wr);
+    const size_t N = (size_t)W * H;
+    hipLaunchKernelGGL(k_gn_prep, p->grid(), p->blk(), 0, st->stream, p->pd);
+    HC(hipMemcpyAsync(p->pd.pO0, pO, N * sizeof(float2), hipMemcpyDeviceToDevice, st->stream));
+    HC(hipMemcpyAsync(p->pd.pA0, pA, N * sizeof(float), hipMemcpyDeviceToDevice, st->stream));
+    hipLaunchKernelGGL(k_pcg_a, p->grid(), p->blk(), 0, st->stream, p->pd, 0);
+    HC(hipMemcpyAsync(outO, p->pd.ApO, N * sizeof(float2), hipMemcpyDeviceToDevice, st->stream));
+    HC(hipMemcpyAsync(outA, p->pd.ApA, N * sizeof(float), hipMemcpyDeviceToDevice, st->stream));
+    hipError_t e = hipStreamSynchronize(st->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    plan_free(p);
+    return (int)e;
+}
+
+int ArapFlow_Cost(Opt_State* st, unsigned W, unsigned H, const void* O, const void* A, const void* U,
+                  const void* C, const void* M, float wf, float wr, double* cost_host)
+{
+    Opt_Plan* p = temp_plan(st, W, H, O, A, U, C, M, wf, wr);
+    hipLaunchKernelGGL(k_cost, p->grid(), p->blk(), 0, st->stream, p->pd, 0);
+    *cost_host = plan_read_cost(p, 0, 0);
+    hipError_t e = hipGetLastError();
+    plan_free(p);
+    return (int)e;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Batched frame solver (ArapFlow_Solver): CombinedSolver on the device
+// ---------------------------------------------------------------------------------------------
+namespace arap {
+
+struct FrameDev {              // per-slot images owned by the frame solver
+    float2 *O, *U, *C, *T, *flow;
+    float *A, *M;
+    uint8_t *mask, *rgb, *out_rgb, *out_mask;
+    unsigned long long* key;
+};
+
+// resetGPU (CombinedSolver.h:207-221): U = O = (x,y), A = 0, Mask = (float)red
+__global__ __launch_bounds__(256) void k_frame_reset(const FrameDev* fr, int W, int N)
+{
+    const FrameDev f = fr[blockIdx.z];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int y = i / W, x = i - y * W;
+    const float2 g = make_float2((float)x, (float)y);
+    f.U[i] = g;
+    f.O[i] = g;
+    f.A[i] = 0.f;
+    f.M[i] = (float)f.mask[i];
+}
+
+// setConstraintImage(alpha) (CombinedSolver.h:223-242).  T holds, per source pixel, the target of the
+// last constraint placed there (host pre-pass in SetFrame, same overwrite order as the reference's
+// loop), or NaN where there is none / where the mask is non-zero.
+__global__ __launch_bounds__(256) void k_frame_ramp(const FrameDev* fr, int W, int N, float alpha)
+{
+    const FrameDev f = fr[blockIdx.z];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float2 t = f.T[i];
+    float2 c = make_float2(-1.0f, -1.0f);
+    if (t.x == t.x) {
+        const int y = i / W, x = i - y * W;
+        c.x = (1.0f - alpha) * (float)x + alpha * t.x;
+        c.y = (1.0f - alpha) * (float)y + alpha * t.y;
+    }
+    f.C[i] = c;
+}
+
+}  // namespace arap
+
+struct ArapFlow_Solver {
+    Opt_State* st = nullptr;
+    int W = 0, H = 0, N = 0, batch = 0;
+    Opt_Plan* plan = nullptr;
+    void* block = nullptr;
+    std::vector<FrameDev> hfr;
+    FrameDev* dfr = nullptr;
+    WarpJob* djobs = nullptr;
+    std::vector<uint8_t> has_rgb;
+    std::vector<uint64_t> nactive;
+    uint64_t last_pcg = 0, last_active = 0, last_grid = 0;
+    unsigned last_n = 0;
+    int last_cost_index = 0;
+};
+
+extern "C" {
+
+ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, unsigned batch)
+{
+    if (!st || W == 0 || H == 0 || batch == 0) return nullptr;
+    HC(hipSetDevice(st->device));
+    ArapFlow_Solver* s = new ArapFlow_Solver();
+    s->st = st; s->W = (int)W; s->H = (int)H; s->N = (int)(W * H); s->batch = (int)batch;
+    s->plan = plan_create(st, (int)W, (int)H, (int)batch);
+    const size_t N = s->N;
+    const size_t sz2 = align_up(N * sizeof(float2), 256), sz1 = align_up(N * sizeof(float), 256);
+    const size_t szb = align_up(N, 256), sz3 = align_up(3 * N, 256), szk = align_up(N * 8, 256);
+    const size_t per = 5 * sz2 + 2 * sz1 + 2 * szb + 2 * sz3 + szk;
+    const size_t tail = align_up(sizeof(FrameDev) * batch, 256) + align_up(sizeof(WarpJob) * batch, 256);
+    HC(hipMalloc(&s->block, per * batch + tail));
+    HC(hipMemsetAsync(s->block, 0, per * batch + tail, st->stream));
+    char* c = (char*)s->block;
+    auto take = [&](size_t b) { char* r = c; c += b; return r; };
+    s->hfr.resize(batch);
+    for (unsigned b = 0; b < batch; ++b) {
+        FrameDev& f = s->hfr[b];
+        f.O = (float2*)take(sz2); f.U = (float2*)take(sz2); f.C = (float2*)take(sz2);
+        f.T = (float2*)take(sz2); f.flow = (float2*)take(sz2);
+        f.A = (float*)take(sz1); f.M = (float*)take(sz1);
+        f.mask = (uint8_t*)take(szb); f.out_mask = (uint8_t*)take(szb);
+        f.rgb = (uint8_t*)take(sz3); f.out_rgb = (uint8_t*)take(sz3);
+        f.key = (unsigned long long*)take(szk);
+    }
+    s->dfr = (FrameDev*)take(align_up(sizeof(FrameDev) * batch, 256));
+    s->djobs = (WarpJob*)take(align_up(sizeof(WarpJob) * batch, 256));
+    HC(hipMemcpyAsync(s->dfr, s->hfr.data(), sizeof(FrameDev) * batch, hipMemcpyHostToDevice, st->stream));
+    HC(hipStreamSynchronize(st->stream));
+    s->has_rgb.assign(batch, 0);
+    s->nactive.assign(batch, 0);
+    const float wfit = sqrtf(100.0f), wreg = sqrtf(0.01f);   // CombinedSolver.h:173-177
+    for (unsigned b = 0; b < batch; ++b) {
+        Slot& sl = s->plan->hslots[b];
+        const FrameDev& f = s->hfr[b];
+        sl.O = f.O; sl.A = f.A; sl.U = f.U; sl.C = f.C; sl.M = f.M;
+        sl.wf = wfit; sl.wr = wreg;
+    }
+    return s;
+}
+
+void ArapFlow_SolverFree(ArapFlow_Solver* s)
+{
+    if (!s) return;
+    plan_free(s->plan);
+    (void)hipFree(s->block);
+    delete s;
+}
+
+int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rgb, const uint8_t* mask_red,
+                            const int32_t* cons, unsigned ncons, int add_border_pins)
+{
+    if (!s || slot >= (unsigned)s->batch || !mask_red || (ncons && !cons)) return -1;
+    const int W = s->W, H = s->H;
+    const size_t N = s->N;
+    // host pre-pass of setConstraintImage's placement loop (CombinedSolver.h:230-240): file
+    // constraints first, then border pins (main.cpp:130-136); later entries overwrite earlier ones;
+    // only where Mask == 0.
+    std::vector<float2> T(N, make_float2(NAN, NAN));
+    auto place = [&](int x, int y, int tx, int ty) {
+        if (x < 0 || x >= W || y < 0 || y >= H) return;
+        if (mask_red[x + (size_t)W * y] == 0) T[x + (size_t)W * y] = make_float2((float)tx, (float)ty);
+    };
+    for (unsigned k = 0; k < ncons; ++k) place(cons[4 * k], cons[4 * k + 1], cons[4 * k + 2], cons[4 * k + 3]);
+    if (add_border_pins)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x)
+                if (y == 0 || x == 0 || y == H - 1 || x == W - 1) place(x, y, x, y);
+    uint64_t na = 0;
+    for (size_t i = 0; i < N; ++i) na += mask_red[i] == 0;
+    s->nactive[slot] = na;
+    HC(hipStreamSynchronize(s->st->stream));
+    const FrameDev& f = s->hfr[slot];
+    HC(hipMemcpy(f.T, T.data(), N * sizeof(float2), hipMemcpyHostToDevice));
+    HC(hipMemcpy(f.mask, mask_red, N, hipMemcpyHostToDevice));
+    if (rgb) HC(hipMemcpy(f.rgb, rgb, 3 * N, hipMemcpyHostToDevice));
+    s->has_rgb[slot] = rgb ? 1 : 0;
+    return 0;
+}
+
+int ArapFlow_SolverSolve(ArapFlow_Solver* s, unsigned nframes, unsigned numIter, unsigned nIterations,
+                         unsigned lIterations)
+{
+    if (!s || nframes == 0 || nframes > (unsigned)s->batch || numIter == 0) return -1;
+    Opt_State* st = s->st;
+    Opt_Plan* p = s->plan;
+    HC(hipSetDevice(st->device));
+    p->nb = (int)nframes;
+    p->sp.nIterations = (int)nIterations;
+    p->sp.lIterations = (int)lIterations;
+    const dim3 g1((s->N + 255) / 256, 1, nframes);
+    // preSingleSolve = resetGPU (CombinedSolver.h:191-193)
+    hipLaunchKernelGGL(k_frame_reset, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N);
+    for (unsigned i = 0; i < numIter; ++i) {
+        const float alpha = (float)(i + 1) / (float)numIter;          // CombinedSolver.h:199-201
+        hipLaunchKernelGGL(k_frame_ramp, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N, alpha);
+        plan_init(p);
+        while (plan_step(p) != 0) {}
+    }
+    s->last_cost_index = p->sp.nIter;
+    s->last_n = nframes;
+    s->last_pcg = (uint64_t)numIter * nIterations * lIterations;
+    s->last_active = 0;
+    for (unsigned b = 0; b < nframes; ++b) s->last_active += s->nactive[b];
+    s->last_grid = (uint64_t)nframes * s->N;
+    return 0;
+}
+
+int ArapFlow_SolverWarp(ArapFlow_Solver* s, unsigned nframes)
+{
+    if (!s || nframes == 0 || nframes > (unsigned)s->batch) return -1;
+    Opt_State* st = s->st;
+    std::vector<WarpJob> jobs(nframes);
+    for (unsigned b = 0; b < nframes; ++b) {
+        const FrameDev& f = s->hfr[b];
+        WarpJob& j = jobs[b];
+        j.field = f.O; j.flow_in = nullptr;
+        j.rgb = s->has_rgb[b] ? f.rgb : nullptr;
+        j.mask = f.mask; j.flow_out = f.flow; j.key = f.key;
+        j.out_rgb = s->has_rgb[b] ? f.out_rgb : nullptr;
+        j.out_mask = f.out_mask;
+    }
+    HC(hipMemcpyAsync(s->djobs, jobs.data(), sizeof(WarpJob) * nframes, hipMemcpyHostToDevice, st->stream));
+    const dim3 g((s->W + 63) / 64, (s->H + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_warp_raster, g, dim3(64, 4), 0, st->stream, s->djobs, s->W, s->H);
+    hipLaunchKernelGGL(k_warp_resolve, dim3((s->N + 255) / 256, 1, nframes), dim3(256), 0, st->stream, s->djobs,
+                       s->N);
+    return 0;
+}
+
+int ArapFlow_SolverGetResults(ArapFlow_Solver* s, unsigned slot, float* flow, uint8_t* warped_rgb,
+                              uint8_t* warped_mask, float* offset, float* angle, double* final_cost)
+{
+    if (!s || slot >= (unsigned)s->batch) return -1;
+    HC(hipStreamSynchronize(s->st->stream));
+    const FrameDev& f = s->hfr[slot];
+    const size_t N = s->N;
+    if (flow) HC(hipMemcpy(flow, f.flow, N * sizeof(float2), hipMemcpyDeviceToHost));
+    if (warped_rgb) HC(hipMemcpy(warped_rgb, f.out_rgb, 3 * N, hipMemcpyDeviceToHost));
+    if (warped_mask) HC(hipMemcpy(warped_mask, f.out_mask, N, hipMemcpyDeviceToHost));
+    if (offset) HC(hipMemcpy(offset, f.O, N * sizeof(float2), hipMemcpyDeviceToHost));
+    if (angle) HC(hipMemcpy(angle, f.A, N * sizeof(float), hipMemcpyDeviceToHost));
+    if (final_cost) *final_cost = plan_read_cost(s->plan, (int)slot, s->last_cost_index);
+    return 0;
+}
+
+int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg, uint64_t* active, uint64_t* grid)
+{
+    if (!s) return -1;
+    if (pcg) *pcg = s->last_pcg;
+    if (active) *active = s->last_active;
+    if (grid) *grid = s->last_grid;
+    return 0;
+}
+
+uint64_t ArapFlow_WarpScratchBytes(unsigned W, unsigned H)
+{
+    return align_up((uint64_t)W * H * 8, 256) + 256;
+}
+
+int ArapFlow_Warp(Opt_State* st, unsigned W, unsigned H, const void* rgb, const void* mask_red, const void* flow,
+                  void* out_rgb, void* out_mask, void* scratch)
+{
+    if (!st || !mask_red || !flow || !out_mask || !scratch) return -1;
+    const size_t N = (size_t)W * H;
+    WarpJob j{};
+    j.field = nullptr; j.flow_in = (const float2*)flow;
+    j.rgb = (const uint8_t*)rgb; j.mask = (const uint8_t*)mask_red;
+    j.flow_out = nullptr;
+    j.key = (unsigned long long*)scratch;
+    j.out_rgb = (uint8_t*)out_rgb; j.out_mask = (uint8_t*)out_mask;
+    WarpJob* dj = (WarpJob*)((char*)scratch + align_up(N * 8, 256));
+    HC(hipMemsetAsync(scratch, 0, N * 8, st->stream));
+    HC(hipMemcpyAsync(dj, &j, sizeof(j), hipMemcpyHostToDevice, st->stream));
+    hipLaunchKernelGGL(k_warp_raster, dim3((W + 63) / 64, (H + 3) / 4, 1), dim3(64, 4), 0, st->stream, dj, (int)W,
+                       (int)H);
+    hipLaunchKernelGGL(k_warp_resolve, dim3((unsigned)((N + 255) / 256), 1, 1), dim3(256), 0, st->stream, dj,
+                       (int)N);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

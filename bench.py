@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- ARAP solve+warp throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch of synthetic frames on every rank: the full
+arap_deform schedule (19 ramp steps x 8 Gauss-Newton steps x 400 PCG iterations,
+ARAP/deformation/src/main.cpp:215-221) for `--batch` independent 854x480 frames, then flow emission
+and the forward rasterisation of RGB and mask.  Inputs (RGB, mask, constraints) are uploaded before
+the timed region.  Workload = BASELINE.json configs[1]: single-segment DAVIS-shaped mask, fd=1.
+Frames shard across ranks with no collective: weak scaling, value = all frames / max time.
+
+One JSON line on rank 0: metric/value/... plus
+  roofline     : dominant PCG kernel; achieved = algorithmic bytes per launch / average launch
+                 duration measured with HIP events around every launch (a separate, un-graphed pass)
+  cpu_baseline : the CPU oracle (kind "port") timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_A, BYTES_B = 64, 96        # algorithmic bytes per vertex per PCG iteration: 16 + 24 floats
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="frames solved concurrently per GPU per step")
+    ap.add_argument("--size", type=int, nargs=2, default=[854, 480], metavar=("W", "H"))
+    ap.add_argument("--schedule", type=int, nargs=3, default=[19, 8, 400], metavar=("NUMITER", "NITER", "LITER"))
+    ap.add_argument("--workload", choices=["davis", "full"], default="davis",
+                    help="davis: configs[1] single-segment mask (~25%% active); full: mask == 0 (roofline config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(frame, schedule):
+    """The CPU oracle (same algorithm, float32, OpenMP over rows) on a bounded sample of the same
+    workload: one ramp step of the same frame (nIterations x lIterations PCG iterations), scaled by
+    the number of ramp steps.  Only this leg of the bench touches oracle/."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    numIter, nIter, lIter = schedule
+    t0 = time.time()
+    orc.frame(frame["mask_red"], frame["constraints"], numIter=1, nIterations=nIter, lIterations=lIter,
+              dtype=np.float32, mode=1, trig=1)
+    dt = time.time() - t0
+    fps = 1.0 / (dt * numIter)
+    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 of %d ramp steps (%d GN x %d PCG iterations) of one frame of the same workload, "
+                      "%.1f s, scaled x%d" % (numIter, nIter, lIter, dt, numIter),
+            "pcg_iters_per_s": nIter * lIter / dt}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from arap_flow_amd import opt, synth
+
+    W, H = a.size
+    B = a.batch
+    numIter, nIter, lIter = a.schedule
+    st = opt.State()
+    fs = opt.FrameSolver(st, W, H, batch=B)
+    frames = [synth.make_frame(W, H, seed=rank * B + b, K=1, fd=1, full_mask=(a.workload == "full"))
+              for b in range(B)]
+    for b, f in enumerate(frames):
+        fs.set_frame(b, f["mask_red"], f["constraints"], rgb=f["rgb"])
+    torch.cuda.synchronize()
+
+    def step():
+        fs.solve(B, numIter, nIter, lIter)
+        fs.warp(B)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    st.timer_begin()
+    for _ in range(a.steps):
+        step()
+    ev_ms = st.timer_end()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = fs.stats()
+    total_frames = world * B * a.steps
+    fps = total_frames / dt
+    pcg_per_frame = stats["pcg_iterations_per_frame"]
+    n_active = stats["active_vertices"] / B          # per frame
+    n_grid = W * H
+
+    out = {
+        "metric": "ARAP solve+warp frames/sec at 854x480 mesh",
+        "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: single %dx%d DAVIS-shaped frame, single-segment mask, fd=1; "
+                               "schedule %d/%d/%d" % (W, H, numIter, nIter, lIter)
+                   if a.workload == "davis" else
+                   "roofline config: %dx%d, mask == 0 (all vertices active), schedule %d/%d/%d"
+                   % (W, H, numIter, nIter, lIter),
+                   "frames_per_gpu_per_step": B, "parallelism": "frames sharded, no collective",
+                   "active_vertices_per_frame": n_active, "grid_vertices_per_frame": n_grid},
+        "pcg_iters_per_s": fps * pcg_per_frame,
+        "hip_event_ms_per_step_rank0": ev_ms / a.steps,
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant PCG kernels: per-launch HIP-event timing, un-graphed pass ----
+        if not a.no_kernel_timing:
+            st.set_kernel_timing(True)
+            fs.solve(B, 1, 1, min(lIter, 100))
+            torch.cuda.synchronize()
+            kt = {k: st.kernel_time(k) for k in ("PCGStepA", "PCGStepB")}
+            st.set_kernel_timing(False)
+            per = {}
+            for k, bytes_v in (("PCGStepA", BYTES_A), ("PCGStepB", BYTES_B)):
+                tot_ms, n = kt[k]
+                avg_s = tot_ms / n * 1e-3
+                per[k] = {"avg_us": avg_s * 1e6, "launches": n,
+                          "GBs_active": bytes_v * n_active * B / avg_s / 1e9,
+                          "GBs_grid": bytes_v * n_grid * B / avg_s / 1e9}
+            dom = max(per, key=lambda k: per[k]["avg_us"])
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": per[dom]["GBs_active"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": per[dom]["GBs_active"] / HBM_PEAK_GBS,
+                               "traffic": None, "avg_launch_us": per[dom]["avg_us"],
+                               "achieved_vs_grid_vertices": per[dom]["GBs_grid"],
+                               "frac_vs_grid_vertices": per[dom]["GBs_grid"] / HBM_PEAK_GBS,
+                               "per_kernel": per,
+                               "note": "algorithmic bytes = %d (A) / %d (B) per ACTIVE vertex per launch x %d frames"
+                                       % (BYTES_A, BYTES_B, B)}
+            # whole-iteration view: 160 B per vertex per PCG iteration over the measured solve time
+            it_s = dt / (a.steps * pcg_per_frame)
+            out["roofline"]["solve_level_GBs_active"] = 160.0 * n_active * B / it_s / 1e9
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames[0], a.schedule)
+        print(json.dumps(out))
+    fs.close()
+    st.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

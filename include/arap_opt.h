@@ -1,0 +1,191 @@
+/*
+ * arap_opt.h -- C ABI of libarapopt.so, the MI355X-native (HIP, gfx950) replacement for the ARAP
+ * hot path of lhoangan/arap_flow.
+ *
+ * Part 1 re-declares, with identical names, argument order and meaning, the ten entry points of the
+ * reference's Opt C API (reference: ARAP/API/release/include/Opt.h:35-71, implemented by the
+ * thunks of ARAP/API/src/createwrapper.t:124-220 around ARAP/API/src/o.t:2521-2558).  A program
+ * written against the reference's Opt.h (ARAP/shared/OptSolver.h:43-91) links against this library
+ * unchanged -- see INTEGRATION.md.
+ *
+ * Part 2 (ArapFlow_*) are additions that have no counterpart symbol in the reference: they move the
+ * work the reference does on the host around each Opt_ProblemSolve (constraint ramp, reset, flow
+ * extraction, triangle rasteriser: ARAP/deformation/src/CombinedSolver.h:199-366,
+ * ARAP/warping/src/main.cpp:110-225) onto the GPU and batch independent frames.
+ *
+ * Plain C: pointers and sizes only.  Device pointers are HIP device pointers.
+ */
+#ifndef ARAP_OPT_H
+#define ARAP_OPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1: the reference's Opt API
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct Opt_State Opt_State;     /* Opt.h:3 */
+typedef struct Opt_Plan Opt_Plan;       /* Opt.h:4 */
+typedef struct Opt_Problem Opt_Problem; /* Opt.h:5 */
+
+/* Opt.h:10-30.  Passed BY VALUE to Opt_NewState.
+ *   doublePrecision            must be 0 (the application never sets it: OptSolver.h:49); a non-zero
+ *                              value makes Opt_NewState print an error and return NULL.
+ *   verbosityLevel             0 silent, >=1 per-GN-step cost lines ("cost: a -> b",
+ *                              solverGPUGaussNewton.t:1160).
+ *   collectPerKernelTimingInfo non-zero: hipEvent brackets around every launch, table printed when
+ *                              the solve ends (util.t:451-511).
+ *   threadsPerBlock            ignored (the tile shape is fixed by the kernels). */
+struct Opt_InitializationParameters {
+    int doublePrecision;
+    int verbosityLevel;
+    int collectPerKernelTimingInfo;
+    int threadsPerBlock;
+};
+typedef struct Opt_InitializationParameters Opt_InitializationParameters;
+
+/* Opt.h:35.  New independent context on the current HIP device.  Never freed by the reference;
+ * ArapFlow_FreeState below is the addition that frees it. */
+Opt_State* Opt_NewState(Opt_InitializationParameters params);
+
+/* Opt.h:40-41.  `filename` is the problem specification.  This library implements exactly one
+ * energy, the one of the reference's arap_plan.t:1-23; the file is read, stripped of comments and
+ * white space, and its declarations are checked against that energy.  Anything else prints a
+ * diagnostic and returns NULL (the reference returns NULL from Opt_ProblemPlan when compilation
+ * fails, o.t:861-881).  The literal name "builtin:arap" selects the energy without a file.
+ * `solverkind`: "gaussNewtonGPU" (what the application uses, CombinedSolverBase.h:75-77);
+ * "LMGPU" is not implemented: diagnostic + NULL. */
+Opt_Problem* Opt_ProblemDefine(Opt_State* state, const char* filename, const char* solverkind);
+void Opt_ProblemDelete(Opt_State* state, Opt_Problem* problem);
+
+/* Opt.h:46-47.  dimensions[0] = W, dimensions[1] = H (Dim("W",0), Dim("H",1), arap_plan.t:1).
+ * Allocates the solver state (solverGPUGaussNewton.t:1254-1284). */
+Opt_Plan* Opt_ProblemPlan(Opt_State* state, Opt_Problem* problem, unsigned int* dimensions);
+void Opt_PlanFree(Opt_State* state, Opt_Plan* plan);
+
+/* Opt.h:51.  `value` points to an int for "nIterations", "lIterations", "residual_reset_period"
+ * and to a float for the nine LM parameters (solverGPUGaussNewton.t:148-163); the LM ones are
+ * stored and otherwise unused on the Gauss-Newton path.  Unknown names print a warning (:1220). */
+void Opt_SetSolverParameter(Opt_State* state, Opt_Plan* plan, const char* name, void* value);
+
+/* Opt.h:56-66.  problemparams is indexed by the plan's declared indices (arap_plan.t:2-8,
+ * unpacked as in util.t:664-692):
+ *   [0] float2* device  Offset      in/out   [1] float*  device  Angle  in/out
+ *   [2] float2* device  UrShape     in       [3] float2* device  Constraints in
+ *   [4] float*  device  Mask        in       [5] float*  HOST    w_fitSqrt
+ *   [6] float*  HOST    w_regSqrt
+ * Images are W*H, row major, x fastest, no padding (o.t:376-387).  The array is re-read on every
+ * Init and every Step (solverGPUGaussNewton.t:960,1026).
+ * Opt_ProblemSolve = Init, then Step until it returns 0 (o.t:2548-2551).
+ * Opt_ProblemStep: one Gauss-Newton iteration = PCGInit1, lIterations PCG iterations, update,
+ * cost (:1016-1177); returns 0 once nIterations steps have been taken. */
+void Opt_ProblemSolve(Opt_State* state, Opt_Plan* plan, void** problemparams);
+void Opt_ProblemInit(Opt_State* state, Opt_Plan* plan, void** problemparams);
+int Opt_ProblemStep(Opt_State* state, Opt_Plan* plan, void** problemparams);
+
+/* Opt.h:71.  Cost after the last completed Init/Step, float upconverted to double
+ * (solverGPUGaussNewton.t:1179-1182).  Synchronises the plan's stream. */
+double Opt_ProblemCurrentCost(Opt_State* state, Opt_Plan* plan);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2: additions (no reference symbol)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Library identification: "arapopt <version> gfx950". */
+const char* ArapFlow_Version(void);
+
+void ArapFlow_FreeState(Opt_State* state);
+
+/* All work of `state` is enqueued on this HIP stream (hipStream_t as void*; NULL = the null
+ * stream, which is what the reference uses: util.t:828). */
+void ArapFlow_SetStream(Opt_State* state, void* hip_stream);
+
+/* hipEvent stopwatch on the state's stream, for callers that have no HIP binding of their own
+ * (bench.py).  Begin records an event; End records a second one, synchronises on it and returns
+ * the elapsed milliseconds. */
+void ArapFlow_TimerBegin(Opt_State* state);
+float ArapFlow_TimerEnd(Opt_State* state);
+
+/* Per-kernel hipEvent timing (the reference's collectPerKernelTimingInfo, Opt.h:23-25, util.t:414-511)
+ * switched at run time.  While on, every kernel launch is bracketed by two events on the stream and
+ * hipGraph replay is disabled.  ArapFlow_KernelTime sums the records of the kernel named
+ * `kernel_name` ("GNPrep", "PCGInit1", "PCGStepA", "PCGStepB", "PCGLinearUpdate", "computeCost")
+ * since timing was switched on; returns -1 if there is none. */
+void ArapFlow_SetKernelTiming(Opt_State* state, int on);
+int ArapFlow_KernelTime(Opt_State* state, const char* kernel_name, double* total_ms, uint64_t* launches);
+
+/* Kernel-level entry points on raw device images, used by the parity tests (tier T1).  All pointers
+ * are device pointers; vectors are split like the unknowns: an Offset-shaped float2 image and an
+ * Angle-shaped float image.  wf/wr = w_fitSqrt/w_regSqrt.  Synchronous.
+ *   ArapFlow_EvalJTF : gradient J^T F and diag(J^T J) of o.t:2129-2172
+ *   ArapFlow_ApplyJTJ: (J^T J P) of o.t:2029-2089
+ *   ArapFlow_Cost    : o.t:2375-2385
+ * Return 0 on success, a HIP error code otherwise. */
+int ArapFlow_EvalJTF(Opt_State* state, unsigned W, unsigned H, const void* Offset, const void* Angle,
+                     const void* UrShape, const void* Constraints, const void* Mask, float wf, float wr,
+                     void* gO, void* gA, void* dO, void* dA);
+int ArapFlow_ApplyJTJ(Opt_State* state, unsigned W, unsigned H, const void* Angle, const void* UrShape,
+                      const void* Constraints, const void* Mask, float wf, float wr, const void* pO,
+                      const void* pA, void* outO, void* outA);
+int ArapFlow_Cost(Opt_State* state, unsigned W, unsigned H, const void* Offset, const void* Angle,
+                  const void* UrShape, const void* Constraints, const void* Mask, float wf, float wr,
+                  double* cost_host);
+
+/* Batched frame solver: the device-resident counterpart of the reference's CombinedSolver
+ * (ARAP/deformation/src/CombinedSolver.h:99-390) driven as in ARAP/deformation/src/main.cpp:140-160.
+ * One object serves frames of one size; `batch` frames are solved concurrently, one set of PCG
+ * scalars per frame.  Frames are independent: no exchange between slots. */
+typedef struct ArapFlow_Solver ArapFlow_Solver;
+
+ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* state, unsigned W, unsigned H, unsigned batch);
+void ArapFlow_SolverFree(ArapFlow_Solver* s);
+
+/* addImage (CombinedSolver.h:139-170) for slot `slot`.  HOST pointers:
+ *   rgb       uint8[H][W][3] or NULL (no warp wanted)
+ *   mask_red  uint8[H][W]    red channel of the mask PNG: 0 = deformable object (CombinedSolver.h:213)
+ *   cons      int32[ncons][4] = x1 y1 x2 y2 rows of the constraint file (main.cpp:26-50), file order
+ *   add_border_pins  non-zero: append (x,y,x,y) for every border pixel (main.cpp:130-136)
+ * Copies to the device on the state's stream (asynchronously; the host buffers are staged
+ * internally and may be reused on return).  Returns 0, or -1 on bad arguments. */
+int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rgb, const uint8_t* mask_red,
+                            const int32_t* cons, unsigned ncons, int add_border_pins);
+
+/* solveAll (CombinedSolverBase.h:23-31,99-120) for slots [0, nframes): reset (CombinedSolver.h:207-221),
+ * then for i < numIter: constraints ramped to alpha = (i+1)/numIter (:199-201,223-242) and one
+ * Opt_ProblemSolve with nIterations/lIterations, unknowns carried over.  The application's values
+ * are 19, 8, 400 (main.cpp:215-221).  Asynchronous on the state's stream. */
+int ArapFlow_SolverSolve(ArapFlow_Solver* s, unsigned nframes, unsigned numIter, unsigned nIterations,
+                         unsigned lIterations);
+
+/* copyResultToCPU + warpField (CombinedSolver.h:280-366) on the device for slots [0, nframes):
+ * flow = Offset - grid, and the forward triangle rasterisation of rgb and mask with the solved
+ * Offset as warp field.  Asynchronous. */
+int ArapFlow_SolverWarp(ArapFlow_Solver* s, unsigned nframes);
+
+/* Synchronise and copy one slot's results to HOST buffers (any may be NULL):
+ *   flow float[H][W][2], warped_rgb uint8[H][W][3], warped_mask uint8[H][W] (255 = object),
+ *   offset float[H][W][2], angle float[H][W], final_cost = Opt_ProblemCurrentCost of the last solve. */
+int ArapFlow_SolverGetResults(ArapFlow_Solver* s, unsigned slot, float* flow, uint8_t* warped_rgb,
+                              uint8_t* warped_mask, float* offset, float* angle, double* final_cost);
+
+/* Counters of the last ArapFlow_SolverSolve (for the bench): number of PCG iterations executed per
+ * frame and number of active (Mask == 0) vertices summed over the solved slots. */
+int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg_iterations_per_frame, uint64_t* active_vertices,
+                         uint64_t* grid_vertices);
+
+/* warp_image (ARAP/warping/src/main.cpp:145-225) on DEVICE buffers: rgb uint8[H][W][3], mask_red
+ * uint8[H][W], flow float[H][W][2] -> out_rgb uint8[H][W][3], out_mask uint8[H][W].
+ * `scratch` is a device buffer of ArapFlow_WarpScratchBytes(W,H) bytes.  Asynchronous on the state's
+ * stream.  Returns 0 or a HIP error code. */
+uint64_t ArapFlow_WarpScratchBytes(unsigned W, unsigned H);
+int ArapFlow_Warp(Opt_State* state, unsigned W, unsigned H, const void* rgb, const void* mask_red,
+                  const void* flow, void* out_rgb, void* out_mask, void* scratch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARAP_OPT_H */

@@ -1,0 +1,55 @@
+"""Shared builders for the parity tests."""
+import numpy as np
+
+
+def random_problem(W, H, seed, generic_urshape=True, mask_frac=0.25, ncons=12):
+    """Random masked problem with non-zero angles, generic UrShape, a negative-target constraint and
+    a duplicate-source constraint (tier T1)."""
+    rng = np.random.default_rng(seed)
+    ys, xs = np.mgrid[0:H, 0:W]
+    grid = np.stack([xs, ys], -1).astype(np.float64)
+    M = (rng.random((H, W)) < mask_frac).astype(np.float64) * 255.0
+    U = grid + (rng.normal(size=(H, W, 2)) * 0.3 if generic_urshape else 0.0)
+    O = U + rng.normal(size=(H, W, 2)) * 0.5
+    A = rng.normal(size=(H, W)) * 0.4
+    C = -np.ones((H, W, 2))
+    for _ in range(ncons):
+        x, y = rng.integers(0, W), rng.integers(0, H)
+        C[y, x] = np.array([x, y]) + rng.normal(size=2) * 2 + 3.0
+    C[H // 2, W // 3] = [-0.5, 4.0]          # negative coordinate: silently inactive (arap_plan.t:22)
+    C[H // 3, W // 2] = [0.0, 0.0]           # exactly zero is valid (greatereq)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    return dict(O=f32(O), A=f32(A), U=f32(U), C=f32(C), M=f32(M), wf=np.float32(10.0), wr=np.float32(0.1))
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    den = np.sqrt((b * b).sum())
+    return np.sqrt(((a - b) ** 2).sum()) / (den if den > 0 else 1.0)
+
+
+def neg_det_quads(flow, act):
+    """number of mesh quads (all four corners active) whose lower-left triangle is inverted"""
+    H, W = act.shape
+    ys, xs = np.mgrid[0:H, 0:W]
+    P = flow + np.stack([xs, ys], -1)
+    a = P[:-1, 1:] - P[:-1, :-1]
+    b = P[1:, :-1] - P[:-1, :-1]
+    det = a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+    q = act[:-1, :-1] & act[:-1, 1:] & act[1:, :-1] & act[1:, 1:]
+    return int(((det < 0) & q).sum())
+
+
+def load_cat512(golden_dir):
+    import os
+    from PIL import Image
+    from arap_flow_amd import flo, opt
+    d = os.path.join(golden_dir, "cat512")
+    rgb = np.array(Image.open(os.path.join(d, "cat512_iRGB.png")).convert("RGB"))
+    mred = np.array(Image.open(os.path.join(d, "cat512_iMsk.png")).convert("RGBA"))[..., 0]
+    cons = opt.load_constraints(os.path.join(d, "cat512_iCstr.txt"))
+    gflow = flo.flow_read(os.path.join(d, "cat512_iFlo.flo"))
+    wrgb = np.array(Image.open(os.path.join(d, "cat512_wRGB.png")).convert("RGB"))
+    wmsk = np.array(Image.open(os.path.join(d, "cat512_wMsk.png")).convert("L"))
+    return dict(rgb=rgb, mask_red=mred, constraints=cons, golden_flow=gflow, golden_wrgb=wrgb, golden_wmsk=wmsk)
