@@ -96,8 +96,11 @@ __device__ __forceinline__ float2 sincos_spec(float af)
 // guardedInvert, CERES variant (solverGPUGaussNewton.t:323-332)
 __device__ __forceinline__ float ginv(float d)
 {
-    const float t = 1.0f + __fsqrt_rn(d);
-    return __fdiv_rn(1.0f, t * t);
+    // sqrtf and '/' are correctly rounded under hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt (the __fsqrt_rn intrinsic is NOT: it is the native
+    // approximate v_sqrt_f32)
+    const float t = 1.0f + sqrtf(d);
+    return 1.0f / (t * t);
 }
 
 __device__ __forceinline__ float dot3(float ax, float ay, float aa, float bx, float by, float ba)

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
         const double* rs = pd.red + (size_t)v.b * pd.nslots * NSHARD;
         const float rhoNew = read_scalar(rs + (size_t)(2 * l) * NSHARD);
         const float rhoOld = read_scalar(rs + (size_t)(2 * l - 2) * NSHARD);
-        if (rhoOld > 0.f) beta = __fdiv_rn(rhoNew, rhoOld);
+        if (rhoOld > 0.f) beta = rhoNew / rhoOld;
     }
     const unsigned f = v.in ? pd.flags[v.g] : 0u;
     double d = 0.0;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
     const float rho = read_scalar(rs + (size_t)(2 * l) * NSHARD);
     const float sigma = read_scalar(rs + (size_t)(2 * l + 1) * NSHARD);
     float alpha = 0.f;
-    if (sigma > 0.f) alpha = __fdiv_rn(rho, sigma);
+    if (sigma > 0.f) alpha = rho / sigma;
     const unsigned f = v.in ? pd.flags[v.g] : 0u;
     double d = 0.0;
     if (f & F_ACT) {

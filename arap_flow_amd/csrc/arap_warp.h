@@ -55,7 +55,7 @@ __device__ __forceinline__ void raster_tri(const WarpJob& j, int W, int H, unsig
             float d12 = X1 * Y2 - Y1 * X2;
             float d20 = X2 * Y0 - Y2 * X0;
             if ((d01 < 0) & (d12 < 0) & (d20 < 0)) continue;
-            const float OneOverD = __fdiv_rn(1.f, (d01 + d12) + d20);
+            const float OneOverD = 1.f / ((d01 + d12) + d20);
             d01 *= OneOverD;
             d12 *= OneOverD;
             d20 *= OneOverD;

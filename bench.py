@@ -50,7 +50,13 @@ def cpu_baseline(frame, schedule):
     workload: one ramp step of the same frame (nIterations x lIterations PCG iterations), scaled by
     the number of ramp steps.  Only this leg of the bench touches oracle/."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    # threads = this process's CPU share (a 1-GPU box grants 16 of the host's cores), not the host total
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("ARAP_CPU_BASELINE_THREADS", "16")))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     numIter, nIter, lIter = schedule
     t0 = time.time()
     orc.frame(frame["mask_red"], frame["constraints"], numIter=1, nIterations=nIter, lIterations=lIter,

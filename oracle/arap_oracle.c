@@ -61,6 +61,11 @@ void arap_sincos_spec(double a, double *c, double *s)
     }
 }
 
+/* cos/sin used by the standalone kernel-level entry points (oracle_evalJTF, oracle_applyJTJ,
+ * oracle_cost, oracle_residuals): 0 = libm, 1 = arap_sincos_spec */
+static int g_oracle_trig = 0;
+void oracle_set_trig(int t) { g_oracle_trig = t; }
+
 #define REAL float
 #define SUF _f32
 #include "arap_oracle_impl.h"

@@ -114,7 +114,7 @@ static void FN(residuals_at)(const FN(Prob) * pb, const REAL *O, const REAL *A, 
 void FN(oracle_residuals)(int W, int H, const REAL *O, const REAL *A, const REAL *U, const REAL *C,
                           const REAL *M, REAL wf, REAL wr, REAL *out /* [N][10] */)
 {
-    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, g_oracle_trig};
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) FN(residuals_at)(&pb, O, A, x, y, out + 10 * (size_t)(x + W * y));
 }
@@ -149,7 +149,7 @@ static double FN(cost_)(const FN(Prob) * pb, const REAL *O, const REAL *A, int m
 double FN(oracle_cost)(int W, int H, const REAL *O, const REAL *A, const REAL *U, const REAL *C,
                        const REAL *M, REAL wf, REAL wr, int mode)
 {
-    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, g_oracle_trig};
     return FN(cost_)(&pb, O, A, mode);
 }
 
@@ -199,7 +199,7 @@ static void FN(evalJTF_at)(const FN(Prob) * pb, const REAL *O, const REAL *A, in
 void FN(oracle_evalJTF)(int W, int H, const REAL *O, const REAL *A, const REAL *U, const REAL *C,
                         const REAL *M, REAL wf, REAL wr, REAL *g /* [N][3] */, REAL *d /* [N][3] */)
 {
-    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, g_oracle_trig};
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             size_t i = (size_t)(x + W * y);
@@ -249,7 +249,7 @@ static void FN(fill_cs)(const FN(Prob) * pb, const REAL *A, REAL *cs)
 void FN(oracle_applyJTJ)(int W, int H, const REAL *A, const REAL *U, const REAL *C, const REAL *M,
                          REAL wf, REAL wr, const REAL *P /* [N][3] */, REAL *out /* [N][3] */)
 {
-    FN(Prob) pb = {W, H, U, C, M, wf, wr, 0};
+    FN(Prob) pb = {W, H, U, C, M, wf, wr, g_oracle_trig};
     size_t N = (size_t)W * H;
     REAL *cs = (REAL *)malloc(sizeof(REAL) * 2 * N);
     FN(fill_cs)(&pb, A, cs);

@@ -35,6 +35,11 @@ def ref_warp_binary():
     return p if os.path.exists(p) else None
 
 
+def set_trig(t):
+    """cos/sin of the standalone kernel-level functions: 0 libm (default), 1 spec routine"""
+    lib().oracle_set_trig(C.c_int(int(t)))
+
+
 def _ct(dtype):
     return C.c_float if dtype == np.float32 else C.c_double
 
