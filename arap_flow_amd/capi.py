@@ -46,6 +46,8 @@ SYMBOLS = [
     ("ArapFlow_SolverWarp", _I, [_VP, _U]),
     ("ArapFlow_SolverGetResults", _I, [_VP, _U, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_double)]),
     ("ArapFlow_SolverStats", _I, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("ArapFlow_SetResident", None, [_VP, _I]),
+    ("ArapFlow_SolverResidentLaunches", C.c_uint64, [_VP]),
     ("ArapFlow_WarpScratchBytes", C.c_uint64, [_U, _U]),
     ("ArapFlow_Warp", _I, [_VP, _U, _U, _VP, _VP, _VP, _VP, _VP, _VP]),
 ]

@@ -142,7 +142,7 @@ __device__ __forceinline__ void block_reduce_atomic(double v, double* target_sha
 // sum of the NSHARD shards of one scalar, by every wavefront for itself (lanes >= NSHARD add 0)
 __device__ __forceinline__ float read_scalar(const double* shards)
 {
-    const unsigned lane = threadIdx.x;
+    const unsigned lane = threadIdx.x & 63u;
     double v = lane < (unsigned)NSHARD
                    ? __hip_atomic_load(shards + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                    : 0.0;

@@ -1,0 +1,412 @@
+// arap_resident.h -- the whole PCG loop of one Gauss-Newton step in ONE launch, state on chip.
+//
+// Why: at 854x480 one PCG iteration moves at most 65 MB, ~10 us at HBM speed, and a DAVIS-shaped frame
+// (25 % of the vertices active) 16 MB; the two dependent global reductions per iteration make a
+// kernel-per-phase solve latency bound (profiles/r01_v1_*: 20-27 us per kernel for 8 frames, 75 % of the
+// workgroups empty).  Here every frame of the batch is solved by a GROUP of 32..256 workgroups (one per CU,
+// 512 threads) that stays resident for all lIterations iterations:
+//   * r, delta and the transient Ap live in registers (8 tile slots of 64x4 vertices per half
+//     workgroup, one vertex per lane per slot); M^-1, flags and tile origins in small LDS tables,
+//   * the search direction p and cos/sin(A) live in LDS as 66x6 halo'd tiles (the stencil reads
+//     every neighbour from LDS),
+//   * per iteration the group exchanges only (a) two 16-byte partial sums per workgroup (all-gather
+//     of data-tagged granules, summed by every workgroup in the same fixed order -> deterministic) and
+//     (b) the preconditioned residual z of tile-border vertices, from which each workgroup rebuilds
+//     its halo of p = z + beta p locally, so there are exactly TWO group-wide waits per iteration,
+//     the two the algorithm cannot avoid.
+// Inter-workgroup visibility follows cdna_hip_programming.md Guideline 16 (R1/R2): handed-off bytes
+// are written with agent-scope (sc1, write-through) stores, every storing wave drains vmcnt(0), the
+// workgroup barriers, ONE lane publishes {tag, value} granules, consumers poll them with sc1 loads
+// and read the payload with sc1 loads only.  Correctness never depends on placement; blockIdx & 7
+// as group id merely tends to keep a group on one XCD.  Every spin is bounded; a timeout sets an error
+// word that the host turns into a hard failure.
+//
+// Arithmetic: the same float32 operation list as k_pcg_a / k_pcg_b (and the CPU oracle), for the
+// pixel-grid UrShape the frame solver always uses (CombinedSolver.h:207-221): d_s = U(c)-U(n) = -s.
+#pragma once
+#include "arap_device.h"
+
+namespace arap {
+
+constexpr int RES_WGS = 256;             // workgroups per launch = CUs of an MI355X, one workgroup per CU
+constexpr int RES_MAX_GROUPS = 8;        // frames in flight per launch: 8, 4, 2 or 1 groups of 32..256 workgroups
+constexpr int RES_THREADS = 512;         // 8 wavefronts: two half-workgroups of 4 (one 64x4 tile each), 2 per SIMD
+constexpr int RES_SLOTS = 8;             // tile slots per half-workgroup (register arrays, fully unrolled)
+constexpr int RES_TILES_PER_WG = 2 * RES_SLOTS;
+constexpr int RES_MAX_HALO = RES_TILES_PER_WG * 136;                 // 2 x 64 + 2 x 4 halo cells per tile
+constexpr int RES_HALO_PER_THREAD = (RES_MAX_HALO + RES_THREADS - 1) / RES_THREADS;   // 5
+constexpr int RES_MAX_TILES = RES_WGS * RES_TILES_PER_WG;   // 4096 tiles (one group of 256 workgroups)
+constexpr int LROW = TILE_X + 2;         // 66
+constexpr int LROWS = TILE_Y + 2;        // 6
+constexpr int LPLANE = LROW * LROWS;     // 396 floats
+constexpr int LTILE = 5 * LPLANE;        // px, py, pa, cos, sin
+constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
+                              + RES_TILES_PER_WG * 256 * 4      // M^-1 of the Angle component
+                              + RES_TILES_PER_WG * 256          // flag bytes
+                              + RES_MAX_HALO * 2                // halo list
+                              + RES_TILES_PER_WG * 8 + 256;     // tile origins, tables, scratch
+constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
+
+struct ResDev {
+    const int* tilelist;        // [batch][RES_MAX_TILES] linear tile index (ty * tilesX + tx) of active tiles
+    const int* ntiles;          // [batch]
+    unsigned long long* gran;   // [groups][2 parity][wgs][2]  {tag << 32 | 32 value bits}; groups*wgs = 256
+    unsigned* err;              // [1] 0 = ok
+    int nframes;                // frames of this launch, <= groups
+    int slot0;                  // first batch slot of this launch
+    int groups;                 // 8, 4, 2 or 1
+    int wgs;                    // workgroups per group = 256 / groups
+};
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ void st_sc1_f2(float2* p, float2 v)
+{
+    unsigned long long u = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    __hip_atomic_store((unsigned long long*)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_f(float* p, float v)
+{
+    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 ld_sc1_f2(const float2* p)
+{
+    const unsigned long long u =
+        __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+}
+__device__ __forceinline__ float ld_sc1_f(const float* p)
+{
+    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Group-wide sum of one double per workgroup.  `part` is this workgroup's partial (valid in wave 0,
+// lane 0).  Wave 0 publishes it as two {tag, 32 bits} granules and sweeps the group's granules until
+// every tag equals `epoch`; lane k owns workgroups k, k+64, ... and adds their partials in that order,
+// then a fixed xor-butterfly adds the lanes, so every workgroup of the group computes the same bits.
+// Returns the sum rounded to float in every thread; false on timeout.
+__device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned long long* gran_group, int rank,
+                                          int wgs, float* bcast /* LDS, 2 floats */, unsigned* err, float& out)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        unsigned long long* buf = gran_group + (size_t)(epoch & 1u) * wgs * 2;
+        part = __shfl(part, 0, 64);
+        if (lane < 2) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(part);
+            const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+            __hip_atomic_store(buf + rank * 2 + lane, ((unsigned long long)epoch << 32) | hw, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double v = 0.0;
+        bool ok = false;
+        for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {
+            v = 0.0;
+            bool mine_ok = true;
+            for (int m = lane; m < wgs; m += 64) {
+                const unsigned long long lo = __hip_atomic_load(buf + 2 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi =
+                    __hip_atomic_load(buf + 2 * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine_ok = mine_ok && (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+                v += __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+            }
+            ok = __all(mine_ok);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) {
+            bcast[0] = (float)v;
+            bcast[1] = ok ? 1.0f : 0.0f;
+            if (!ok) atomicExch(err, 0xDEAD0000u | (epoch & 0xffffu));
+        }
+    }
+    __syncthreads();
+    out = bcast[0];
+    const bool good = bcast[1] != 0.0f;
+    __syncthreads();      // bcast may be rewritten by the next call
+    return good;
+}
+
+// block-wide sum of a double over the 8 wavefronts; result valid in wave 0 lane 0
+__device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 8 doubles */)
+{
+    v = wave_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (wave == 0 && lane == 0) {
+#pragma unroll
+        for (int w = 0; w < RES_THREADS / 64; ++w) t += wsum[w];
+    }
+    return t;
+}
+
+// grid = 256 workgroups (groups x wgs), block = 512, dynamic LDS = RES_LDS_BYTES
+//
+// LDS map: 16 halo'd tiles x {px,py,pa,cos,sin} (126 720 B); M^-1_A [16][256] floats; flag bytes
+// [16][256]; halo list (u16 cell ids, <= 2176); tile origins int2[16]; the 10-entry M^-1_O table;
+// broadcast + reduction scratch.  Registers per lane: r(3) delta(3) Ap(3) for each of 8 slots = 72.
+// Wavefronts 0-3 (half 0) own the even local tiles, wavefronts 4-7 (half 1) the odd ones.
+__global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, ResDev rd, int L)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = blockIdx.x % rd.groups;              // tends to keep a group on one XCD (speed only)
+    const int rank = blockIdx.x / rd.groups;
+    if (g >= rd.nframes) return;                       // whole groups leave together
+    const int b = rd.slot0 + g;
+    const int wgs = rd.wgs;
+    const int W = pd.W, H = pd.H;
+    const size_t gb = (size_t)b * pd.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = wave >> 2, wy = wave & 3;         // half-workgroup; row inside the tile
+    const int t256 = tid & 255;                        // thread index inside the half = position in the tile
+    float* maT = lds + RES_TILES_PER_WG * LTILE;                          // [16][256]
+    unsigned char* flT = (unsigned char*)(maT + RES_TILES_PER_WG * 256);  // [16][256]
+    unsigned short* hlist = (unsigned short*)(flT + RES_TILES_PER_WG * 256);   // [RES_MAX_HALO]
+    int2* tbase = (int2*)(hlist + RES_MAX_HALO);                          // [16] tile origin (x0, y0) or (-1,-1)
+    float* moLUT = (float*)(tbase + RES_TILES_PER_WG);                    // [10] (+2 pad)
+    float* bcast = moLUT + 12;                                            // 2 floats + nhalo (int) + pad
+    int* nhalo = (int*)(bcast + 2);
+    double* wsum = (double*)(bcast + 4);                                  // 8 doubles
+    unsigned long long* gran_group = rd.gran + (size_t)g * 2 * wgs * 2;
+
+    const int nt = rd.ntiles[b];
+    const int tp = (nt + wgs - 1) / wgs;                                  // tiles per workgroup (<= 16)
+    const int* tl = rd.tilelist + (size_t)b * RES_MAX_TILES;
+    float wr2, wf2;
+    {
+        const Slot sl = pd.slots[b];
+        wr2 = sl.wr * sl.wr;
+        wf2 = sl.wf * sl.wf;
+        // M^-1 of the Offset components as k_gn_init computes it: D_O = sum over valid edges of
+        // (wr*wr + wr*wr), plus wf*wf if the fit term is on; it depends on (degree, fit) only.
+        if (tid < 10) {
+            const int deg = tid % 5, fit = tid / 5;
+            float dO = 0.f;
+            for (int k = 0; k < deg; ++k) dO = dO + (sl.wr * sl.wr + sl.wr * sl.wr);
+            if (fit) dO = dO + sl.wf * sl.wf;
+            moLUT[tid] = ginv(dO);
+        }
+        if (tid == 0) *nhalo = 0;
+    }
+
+    float rx[RES_SLOTS], ry[RES_SLOTS], ra[RES_SLOTS];
+    float dx_[RES_SLOTS], dy_[RES_SLOTS], da_[RES_SLOTS];
+    float apx[RES_SLOTS], apy[RES_SLOTS], apa[RES_SLOTS];
+
+    // cell (row, col) of plane k of local tile t : lds[t*LTILE + k*LPLANE + row*LROW + col]
+    const int cell = (wy + 1) * LROW + (lane + 1);
+
+    // ---- prologue: load state, p0 and cos/sin with halos ------------------------------------------
+#pragma unroll
+    for (int j = 0; j < RES_SLOTS; ++j) {
+        const int k = 2 * j + half;                    // local tile of this half in slot j
+        const int gt = rank * tp + k;                  // position in the frame's active-tile list
+        rx[j] = ry[j] = ra[j] = 0.f; dx_[j] = dy_[j] = da_[j] = 0.f;
+        apx[j] = apy[j] = apa[j] = 0.f;
+        unsigned f = 0;
+        float mA = 0.f;
+        int x0 = -1, y0 = -1;
+        if (k < tp && gt < nt) {
+            const int tile = tl[gt];
+            const int ty = tile / pd.tilesX, tx = tile - ty * pd.tilesX;
+            x0 = tx * TILE_X; y0 = ty * TILE_Y;
+            const int x = x0 + lane, y = y0 + wy;
+            float* T = lds + k * LTILE;
+            if (x < W && y < H) {
+                const int i = x + W * y;
+                f = pd.flags[gb + i];
+                const float2 p0 = pd.pO0[gb + i], cs = pd.cs[gb + i];
+                T[0 * LPLANE + cell] = p0.x; T[1 * LPLANE + cell] = p0.y; T[2 * LPLANE + cell] = pd.pA0[gb + i];
+                T[3 * LPLANE + cell] = cs.x; T[4 * LPLANE + cell] = cs.y;
+                if (f & F_ACT) {
+                    const float2 r = pd.rO[gb + i];
+                    rx[j] = r.x; ry[j] = r.y; ra[j] = pd.rA[gb + i];
+                    mA = pd.preA[gb + i];
+                }
+                // halo cells this thread is responsible for
+                int hi = -1, hc = 0;
+                if (wy == 0 && y0 > 0) { hi = i - W; hc = 0 * LROW + (lane + 1); }
+                if (wy == 3 && y + 1 < H) { hi = i + W; hc = 5 * LROW + (lane + 1); }
+                if (hi >= 0) {
+                    const float2 hp = pd.pO0[gb + hi], hcs = pd.cs[gb + hi];
+                    T[0 * LPLANE + hc] = hp.x; T[1 * LPLANE + hc] = hp.y; T[2 * LPLANE + hc] = pd.pA0[gb + hi];
+                    T[3 * LPLANE + hc] = hcs.x; T[4 * LPLANE + hc] = hcs.y;
+                }
+                hi = -1;
+                if (lane == 0 && x0 > 0) { hi = i - 1; hc = (wy + 1) * LROW + 0; }
+                if (lane == 63 && x + 1 < W) { hi = i + 1; hc = (wy + 1) * LROW + 65; }
+                if (hi >= 0) {
+                    const float2 hp = pd.pO0[gb + hi], hcs = pd.cs[gb + hi];
+                    T[0 * LPLANE + hc] = hp.x; T[1 * LPLANE + hc] = hp.y; T[2 * LPLANE + hc] = pd.pA0[gb + hi];
+                    T[3 * LPLANE + hc] = hcs.x; T[4 * LPLANE + hc] = hcs.y;
+                }
+            }
+        }
+        flT[k * 256 + t256] = (unsigned char)f;
+        maT[k * 256 + t256] = mA;
+        if (t256 == 0) tbase[k] = make_int2(x0, y0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float rho = read_scalar(pd.red + ((size_t)b * pd.nslots + 0) * NSHARD);     // rho_0 from k_gn_init
+    __syncthreads();
+    // ---- halo list: every halo cell whose adjacent interior vertex has the matching edge bit ------------
+    // candidate c of tile k: [0,64) top row, [64,128) bottom row, [128,132) left column, [132,136) right
+    for (int c = tid; c < RES_TILES_PER_WG * 136; c += RES_THREADS) {
+        const int k = c / 136, q = c - k * 136;
+        int row, col;
+        unsigned f;
+        if (q < 64) { row = 0; col = q + 1; f = flT[k * 256 + 0 * 64 + q] & F_E3; }
+        else if (q < 128) { row = 5; col = q - 64 + 1; f = flT[k * 256 + 3 * 64 + (q - 64)] & F_E2; }
+        else if (q < 132) { row = q - 128 + 1; col = 0; f = flT[k * 256 + (q - 128) * 64 + 0] & F_E1; }
+        else { row = q - 132 + 1; col = 65; f = flT[k * 256 + (q - 132) * 64 + 63] & F_E0; }
+        if (f) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(k * LPLANE + row * LROW + col);
+    }
+    __syncthreads();
+    const int nh = *nhalo;
+
+    bool alive = true;
+    for (int l = 0; l < L && alive; ++l) {
+        // ---------------- phase A: Ap = J^T J p, sigma = p.Ap --------------------------------------
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < RES_SLOTS; ++j) {
+            const int k = 2 * j + half;
+            const unsigned f = flT[k * 256 + t256];
+            if (f & F_ACT) {
+                const float* T = lds + k * LTILE;
+                const float px_ = T[0 * LPLANE + cell], py_ = T[1 * LPLANE + cell], pa_ = T[2 * LPLANE + cell];
+                const float ci = T[3 * LPLANE + cell], si = T[4 * LPLANE + cell];
+                float ax = 0.f, ay = 0.f, aa = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if (!(f & (1u << s))) continue;
+                    const int nc = cell + (s == 0 ? 1 : (s == 1 ? -1 : (s == 2 ? LROW : -LROW)));
+                    const float qOx = T[0 * LPLANE + nc], qOy = T[1 * LPLANE + nc], qA = T[2 * LPLANE + nc];
+                    const float cn = T[3 * LPLANE + nc], sn = T[4 * LPLANE + nc];
+                    // d = U(c) - U(n) on the pixel grid
+                    const float dx = s == 0 ? -1.f : (s == 1 ? 1.f : 0.f);
+                    const float dy = s == 2 ? -1.f : (s == 3 ? 1.f : 0.f);
+                    const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
+                    const float hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;
+                    const float ex = px_ - qOx, ey = py_ - qOy;
+                    const float tx = ex - qx * pa_, ty = ey - qy * pa_;
+                    ax = ax + wr2 * ((ex + tx) - hx * qA);
+                    ay = ay + wr2 * ((ey + ty) - hy * qA);
+                    aa = aa - wr2 * (qx * tx + qy * ty);
+                }
+                if (f & F_FIT) {
+                    ax = ax + wf2 * px_;
+                    ay = ay + wf2 * py_;
+                }
+                apx[j] = ax; apy[j] = ay; apa[j] = aa;
+                acc += (double)dot3(px_, py_, pa_, ax, ay, aa);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float sigma;
+        alive = group_sum(block_sum8(acc, wsum), 2u * l + 1u, gran_group, rank, wgs, bcast, rd.err, sigma);
+        if (!alive) break;
+        // ---------------- phase B: alpha, delta, r, z, rho' -----------------------------------------
+        float alpha = 0.f;
+        if (sigma > 0.f) alpha = rho / sigma;
+        acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < RES_SLOTS; ++j) {
+            const int k = 2 * j + half;
+            const unsigned f = flT[k * 256 + t256];
+            if (f & F_ACT) {
+                const float* T = lds + k * LTILE;
+                const float px_ = T[0 * LPLANE + cell], py_ = T[1 * LPLANE + cell], pa_ = T[2 * LPLANE + cell];
+                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = maT[k * 256 + t256];
+                const int2 tb = tbase[k];
+                const int i = tb.x + lane + W * (tb.y + wy);
+                dx_[j] = dx_[j] + alpha * px_;
+                dy_[j] = dy_[j] + alpha * py_;
+                da_[j] = da_[j] + alpha * pa_;
+                rx[j] = rx[j] - alpha * apx[j];
+                ry[j] = ry[j] - alpha * apy[j];
+                ra[j] = ra[j] - alpha * apa[j];
+                const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
+                st_sc1_f2(pd.zO + gb + i, make_float2(zx, zy));
+                st_sc1_f(pd.zA + gb + i, za);
+                acc += (double)dot3(zx, zy, za, rx[j], ry[j], ra[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains (R1)
+        float rhoNew;
+        alive = group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, rhoNew);
+        if (!alive) break;
+        float beta = 0.f;
+        if (rho > 0.f) beta = rhoNew / rho;
+        rho = rhoNew;
+        if (l + 1 == L) break;
+        // ---------------- p = z + beta p ---------------------------------------------------------------
+        // (1) issue the sc1 loads of the neighbours' z for every halo cell of the workgroup (all in flight)
+        float2 hz2[RES_HALO_PER_THREAD];
+        float hz1[RES_HALO_PER_THREAD];
+        int hcell[RES_HALO_PER_THREAD];
+#pragma unroll
+        for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
+            const int c = tid + u * RES_THREADS;
+            hcell[u] = -1;
+            hz2[u] = make_float2(0.f, 0.f);
+            hz1[u] = 0.f;
+            if (c < nh) {
+                const int id = hlist[c];
+                const int k = id / LPLANE, rem = id - k * LPLANE;
+                const int row = rem / LROW, col = rem - row * LROW;
+                const int2 tb = tbase[k];
+                const int hi = (tb.x + col - 1) + W * (tb.y + row - 1);
+                hcell[u] = k * LTILE + rem;
+                hz2[u] = ld_sc1_f2(pd.zO + gb + hi);
+                hz1[u] = ld_sc1_f(pd.zA + gb + hi);
+            }
+        }
+        // (2) own cells while those loads fly
+#pragma unroll
+        for (int j = 0; j < RES_SLOTS; ++j) {
+            const int k = 2 * j + half;
+            const unsigned f = flT[k * 256 + t256];
+            if (f & F_ACT) {
+                float* T = lds + k * LTILE;
+                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = maT[k * 256 + t256];
+                const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
+                T[0 * LPLANE + cell] = zx + beta * T[0 * LPLANE + cell];
+                T[1 * LPLANE + cell] = zy + beta * T[1 * LPLANE + cell];
+                T[2 * LPLANE + cell] = za + beta * T[2 * LPLANE + cell];
+            }
+        }
+        // (3) halo cells: p_halo = z_halo + beta p_halo (the owner computes the same expression)
+#pragma unroll
+        for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
+            if (hcell[u] >= 0) {
+                float* Tc = lds + hcell[u];
+                Tc[0 * LPLANE] = hz2[u].x + beta * Tc[0 * LPLANE];
+                Tc[1 * LPLANE] = hz2[u].y + beta * Tc[1 * LPLANE];
+                Tc[2 * LPLANE] = hz1[u] + beta * Tc[2 * LPLANE];
+            }
+        }
+        __syncthreads();
+    }
+    if (!alive) return;
+    // ---- epilogue: delta back to the plan images for k_gn_update --------------------------------------
+#pragma unroll
+    for (int j = 0; j < RES_SLOTS; ++j) {
+        const int k = 2 * j + half;
+        const unsigned f = flT[k * 256 + t256];
+        if (f & F_ACT) {
+            const int2 tb = tbase[k];
+            const int i = tb.x + lane + W * (tb.y + wy);
+            pd.deltaO[gb + i] = make_float2(dx_[j], dy_[j]);
+            pd.deltaA[gb + i] = da_[j];
+        }
+    }
+}
+
+}  // namespace arap

@@ -22,6 +22,7 @@
 
 #include "../../include/arap_opt.h"
 #include "arap_kernels.h"
+#include "arap_resident.h"
 #include "arap_warp.h"
 
 using namespace arap;
@@ -79,6 +80,7 @@ struct Opt_State {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     KernelTimer ktimer;
     bool use_graph = true;
+    bool use_resident = true;   // ArapFlow_SetResident
 };
 
 struct Opt_Problem {
@@ -109,10 +111,17 @@ struct Opt_Plan {
     // graph of one GN step, keyed by (lIterations, nb)
     hipGraphExec_t gexec = nullptr;
     hipGraph_t graph = nullptr;
-    int g_l = -1, g_nb = -1;
+    int g_l = -1, g_nb = -1, g_res = -1;
     double prevCost[1] = {0.0};
     bool cost_valid = false;
     int cost_index = 0;
+    // resident PCG (arap_resident.h): only for the frame solver (pixel-grid UrShape, host-known masks)
+    bool res_capable = false;       // device has 256 CUs and the kernel fits one workgroup per CU
+    bool res_frames = false;        // plan is driven by ArapFlow_Solver
+    ResDev rd{};
+    void* res_block = nullptr;
+    std::vector<int> h_ntiles;
+    unsigned res_launches = 0;
 
     dim3 grid() const { return dim3(pd.tilesX, pd.tilesY, nb); }
     dim3 blk() const { return dim3(TILE_X, TILE_Y, 1); }
@@ -151,14 +160,76 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     pd.slots = (Slot*)take(szs);
     pd.red = nullptr; pd.costred = nullptr; pd.nslots = 0; pd.ncost = 0;
     p->hslots.assign(batch, Slot{});
+    p->h_ntiles.assign(batch, 0);
     return p;
+}
+
+// resident-path resources: active-tile lists, granules, error word
+static void plan_enable_resident(Opt_Plan* p)
+{
+    Opt_State* st = p->st;
+    const char* nr = getenv("ARAPOPT_NO_RESIDENT");
+    if (nr && nr[0] == '1') return;
+    hipDeviceProp_t prop;
+    HC(hipGetDeviceProperties(&prop, st->device));
+    if (prop.multiProcessorCount < RES_WGS) return;
+    if (hipFuncSetAttribute((const void*)k_pcg_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            RES_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return; }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pcg_resident, RES_THREADS,
+                                                     RES_LDS_BYTES) != hipSuccess || occ < 1) {
+        (void)hipGetLastError();
+        return;
+    }
+    const size_t sz_tl = align_up((size_t)p->batch * RES_MAX_TILES * sizeof(int), 256);
+    const size_t sz_nt = align_up((size_t)p->batch * sizeof(int), 256);
+    const size_t sz_gr = align_up((size_t)2 * RES_WGS * 2 * 8, 256);
+    HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256));
+    HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256, st->stream));
+    char* c = (char*)p->res_block;
+    p->rd.gran = (unsigned long long*)c; c += sz_gr;       // granules first: the per-launch memset zeroes
+    p->rd.tilelist = (const int*)c; c += sz_tl;            // exactly this 16-byte-multiple block
+    p->rd.ntiles = (const int*)c; c += sz_nt;
+    p->rd.err = (unsigned*)c;
+    p->res_capable = true;
+    p->res_frames = true;
+}
+
+static bool plan_resident_eligible(const Opt_Plan* p)
+{
+    if (!p->res_capable || !p->res_frames || p->st->timing || !p->st->use_resident) return false;
+    for (int b = 0; b < p->nb; ++b)
+        if (p->h_ntiles[b] > RES_MAX_TILES) return false;
+    return true;
+}
+
+// frames in flight per resident launch: the most groups whose workgroups can hold the largest frame
+static int plan_resident_groups(const Opt_Plan* p)
+{
+    int mx = 1;
+    for (int b = 0; b < p->nb; ++b) mx = p->h_ntiles[b] > mx ? p->h_ntiles[b] : mx;
+    int groups = RES_MAX_GROUPS;
+    while (groups > 1 && (RES_WGS / groups) * RES_TILES_PER_WG < mx) groups >>= 1;
+    while (groups > 1 && groups / 2 >= p->nb) groups >>= 1;      // fewer frames than groups: widen the groups
+    return groups;
+}
+
+static void plan_check_resident_error(Opt_Plan* p)
+{
+    if (!p->res_capable || p->res_launches == 0) return;
+    unsigned e = 0;
+    HC(hipMemcpy(&e, p->rd.err, sizeof(e), hipMemcpyDeviceToHost));
+    if (e != 0) {
+        fprintf(stderr, "arapopt: resident PCG kernel timed out at a group barrier (code 0x%08x)\n", e);
+        exit(3);
+    }
 }
 
 static void plan_drop_graph(Opt_Plan* p)
 {
     if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
     if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
-    p->g_l = p->g_nb = -1;
+    p->g_l = p->g_nb = p->g_res = -1;
 }
 
 static void plan_free(Opt_Plan* p)
@@ -168,6 +239,7 @@ static void plan_free(Opt_Plan* p)
     plan_drop_graph(p);
     if (p->pd.red) (void)hipFree(p->pd.red);
     if (p->pd.costred) (void)hipFree(p->pd.costred);
+    if (p->res_block) (void)hipFree(p->res_block);
     if (p->block) (void)hipFree(p->block);
     delete p;
 }
@@ -229,9 +301,24 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
     HC(hipMemsetAsync(p->pd.red, 0, (size_t)p->nb * p->pd.nslots * NSHARD * sizeof(double), s));
     LAUNCH(p, s, "GNPrep", k_gn_prep, g, b, p->pd);
     LAUNCH(p, s, "PCGInit1", k_gn_init, g, b, p->pd);
-    for (int l = 0; l < L; ++l) {
-        LAUNCH(p, s, "PCGStepA", k_pcg_a, g, b, p->pd, l);
-        LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
+    if (plan_resident_eligible(p)) {
+        // all L iterations in one launch, state on chip (arap_resident.h).  Granule tags restart at 1
+        // in every launch, so the granule block is zeroed first (cdna guide G16 "re-initialise every call").
+        ResDev rd = p->rd;
+        rd.groups = plan_resident_groups(p);
+        rd.wgs = RES_WGS / rd.groups;
+        for (int s0 = 0; s0 < p->nb; s0 += rd.groups) {
+            rd.slot0 = s0;
+            rd.nframes = p->nb - s0 < rd.groups ? p->nb - s0 : rd.groups;
+            HC(hipMemsetAsync(rd.gran, 0, (size_t)2 * RES_WGS * 2 * 8, s));
+            hipLaunchKernelGGL(k_pcg_resident, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
+            p->res_launches++;
+        }
+    } else {
+        for (int l = 0; l < L; ++l) {
+            LAUNCH(p, s, "PCGStepA", k_pcg_a, g, b, p->pd, l);
+            LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
+        }
     }
     LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, g, b, p->pd);
 }
@@ -244,7 +331,8 @@ static void plan_gn_step(Opt_Plan* p)
         enqueue_gn_step(p, st->stream);
         return;
     }
-    if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb) {
+    const int res_now = plan_resident_eligible(p) ? 1 : 0;
+    if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
         enqueue_gn_step(p, st->cap);
@@ -252,6 +340,7 @@ static void plan_gn_step(Opt_Plan* p)
         HC(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
         p->g_l = p->sp.lIterations;
         p->g_nb = p->nb;
+        p->g_res = res_now;
     }
     HC(hipGraphLaunch(p->gexec, st->stream));
 }
@@ -271,6 +360,7 @@ static double plan_read_cost(Opt_Plan* p, int b, int index)
     HC(hipMemcpyAsync(sh, p->pd.costred + ((size_t)b * p->pd.ncost + index) * NSHARD, sizeof(sh),
                       hipMemcpyDeviceToHost, p->st->stream));
     HC(hipStreamSynchronize(p->st->stream));
+    plan_check_resident_error(p);
     double t = 0.0;
     for (int i = 0; i < NSHARD; ++i) t += sh[i];
     return (double)(float)t;
@@ -506,6 +596,8 @@ double Opt_ProblemCurrentCost(Opt_State*, Opt_Plan* plan)
 // ---------------------------------------------------------------------------------------------
 const char* ArapFlow_Version(void) { return ARAPOPT_VERSION; }
 
+void ArapFlow_SetResident(Opt_State* state, int on) { state->use_resident = on != 0; }
+
 void ArapFlow_SetKernelTiming(Opt_State* state, int on)
 {
     HC(hipStreamSynchronize(state->stream));
@@ -672,6 +764,7 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
     ArapFlow_Solver* s = new ArapFlow_Solver();
     s->st = st; s->W = (int)W; s->H = (int)H; s->N = (int)(W * H); s->batch = (int)batch;
     s->plan = plan_create(st, (int)W, (int)H, (int)batch);
+    plan_enable_resident(s->plan);
     const size_t N = s->N;
     const size_t sz2 = align_up(N * sizeof(float2), 256), sz1 = align_up(N * sizeof(float), 256);
     const size_t szb = align_up(N, 256), sz3 = align_up(3 * N, 256), szk = align_up(N * 8, 256);
@@ -737,7 +830,28 @@ int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rg
     uint64_t na = 0;
     for (size_t i = 0; i < N; ++i) na += mask_red[i] == 0;
     s->nactive[slot] = na;
+    // active 64x4 tiles of this frame, row-major (resident path work list)
+    std::vector<int> tiles;
+    {
+        const int tX = s->plan->pd.tilesX, tY = s->plan->pd.tilesY;
+        for (int ty = 0; ty < tY; ++ty)
+            for (int tx = 0; tx < tX; ++tx) {
+                bool any = false;
+                for (int y = ty * TILE_Y; y < H && y < (ty + 1) * TILE_Y && !any; ++y)
+                    for (int x = tx * TILE_X; x < W && x < (tx + 1) * TILE_X; ++x)
+                        if (mask_red[x + (size_t)W * y] == 0) { any = true; break; }
+                if (any) tiles.push_back(ty * tX + tx);
+            }
+    }
+    s->plan->h_ntiles[slot] = (int)tiles.size();
     HC(hipStreamSynchronize(s->st->stream));
+    if (s->plan->res_capable) {
+        const int nt = (int)tiles.size();
+        if (nt <= RES_MAX_TILES && nt > 0)
+            HC(hipMemcpy((void*)(s->plan->rd.tilelist + (size_t)slot * RES_MAX_TILES), tiles.data(),
+                         sizeof(int) * nt, hipMemcpyHostToDevice));
+        HC(hipMemcpy((void*)(s->plan->rd.ntiles + slot), &nt, sizeof(int), hipMemcpyHostToDevice));
+    }
     const FrameDev& f = s->hfr[slot];
     HC(hipMemcpy(f.T, T.data(), N * sizeof(float2), hipMemcpyHostToDevice));
     HC(hipMemcpy(f.mask, mask_red, N, hipMemcpyHostToDevice));
@@ -801,6 +915,7 @@ int ArapFlow_SolverGetResults(ArapFlow_Solver* s, unsigned slot, float* flow, ui
 {
     if (!s || slot >= (unsigned)s->batch) return -1;
     HC(hipStreamSynchronize(s->st->stream));
+    plan_check_resident_error(s->plan);
     const FrameDev& f = s->hfr[slot];
     const size_t N = s->N;
     if (flow) HC(hipMemcpy(flow, f.flow, N * sizeof(float2), hipMemcpyDeviceToHost));
@@ -820,6 +935,8 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg, uint64_t* active, ui
     if (grid) *grid = s->last_grid;
     return 0;
 }
+
+uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s) { return s ? s->plan->res_launches : 0; }
 
 uint64_t ArapFlow_WarpScratchBytes(unsigned W, unsigned H)
 {

@@ -48,6 +48,10 @@ class State:
     def timer_end(self):
         return float(self.lib.ArapFlow_TimerEnd(self.handle))
 
+    def set_resident(self, on):
+        """allow (default) / forbid the on-chip resident PCG kernel of the frame solver"""
+        self.lib.ArapFlow_SetResident(self.handle, int(bool(on)))
+
     def set_kernel_timing(self, on):
         self.lib.ArapFlow_SetKernelTiming(self.handle, int(bool(on)))
 
@@ -300,7 +304,8 @@ class FrameSolver:
     def stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.lib.ArapFlow_SolverStats(self.h, C.byref(a), C.byref(b), C.byref(c))
-        return dict(pcg_iterations_per_frame=a.value, active_vertices=b.value, grid_vertices=c.value)
+        return dict(pcg_iterations_per_frame=a.value, active_vertices=b.value, grid_vertices=c.value,
+                    resident_launches=int(self.lib.ArapFlow_SolverResidentLaunches(self.h)))
 
     def close(self):
         if self.h:

@@ -177,6 +177,14 @@ int ArapFlow_SolverGetResults(ArapFlow_Solver* s, unsigned slot, float* flow, ui
 int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg_iterations_per_frame, uint64_t* active_vertices,
                          uint64_t* grid_vertices);
 
+/* The frame solver runs the PCG loop of a Gauss-Newton step either as two kernels per iteration
+ * replayed from a hipGraph, or -- when every frame's active 64x4 tiles fit on chip -- as ONE resident
+ * launch that keeps the PCG state in registers/LDS.  Both perform the same float32
+ * operations; results are identical.  ArapFlow_SetResident(state, 0) forces the two-kernel path;
+ * ArapFlow_SolverResidentLaunches counts resident launches since the solver was created. */
+void ArapFlow_SetResident(Opt_State* state, int on);
+uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s);
+
 /* warp_image (ARAP/warping/src/main.cpp:145-225) on DEVICE buffers: rgb uint8[H][W][3], mask_red
  * uint8[H][W], flow float[H][W][2] -> out_rgb uint8[H][W][3], out_mask uint8[H][W].
  * `scratch` is a device buffer of ArapFlow_WarpScratchBytes(W,H) bytes.  Asynchronous on the state's

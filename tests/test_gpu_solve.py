@@ -161,3 +161,28 @@ def test_T4_full_schedule_cat512_vs_reference_golden(gpu_state, golden_dir):
     # the warped outputs of that solve vs the reference's committed PNGs: the fields differ by the
     # rounding-trajectory noise above, so compare coverage, not pixels
     assert (r["warped_mask"] != cat["golden_wmsk"]).mean() < 0.01
+
+
+def test_resident_and_two_kernel_paths_are_bit_identical(gpu_state):
+    """The on-chip resident PCG kernel and the two-kernels-per-iteration path perform the same float32
+    operation list: identical Offset/Angle bits.  Covers 8, 4 and 1 frames in flight and a frame that is
+    too large for eight groups (so the groups widen)."""
+    from arap_flow_amd import synth
+    cases = [(854, 480, 5, 1, (2, 2, 60)), (320, 200, 2, 3, (3, 2, 40)), (200, 120, 8, 1, (1, 3, 25))]
+    for W, H, nfr, K, sched in cases:
+        frames = [synth.make_frame(W, H, seed=10 + s, K=K, fd=2) for s in range(nfr)]
+        outs = []
+        for resident in (True, False):
+            gpu_state.set_resident(resident)
+            fs = opt.FrameSolver(gpu_state, W, H, batch=nfr)
+            for b, f in enumerate(frames):
+                fs.set_frame(b, f["mask_red"], f["constraints"])
+            fs.solve(nfr, *sched)
+            outs.append([fs.results(b, want_rgb=False) for b in range(nfr)])
+            st = fs.stats()
+            assert (st["resident_launches"] > 0) == resident
+            fs.close()
+        gpu_state.set_resident(True)
+        for a, b in zip(*outs):
+            assert np.array_equal(a["offset"], b["offset"]) and np.array_equal(a["angle"], b["angle"])
+            assert a["cost"] == b["cost"]
