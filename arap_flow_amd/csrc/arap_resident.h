@@ -3,10 +3,11 @@
 // Why: at 854x480 one PCG iteration moves at most 65 MB, ~10 us at HBM speed, and a DAVIS-shaped frame
 // (25 % of the vertices active) 16 MB; the two dependent global reductions per iteration make a
 // kernel-per-phase solve latency bound (profiles/r01_v1_*: 20-27 us per kernel for 8 frames, 75 % of the
-// workgroups empty).  Here every frame of the batch is solved by a GROUP of 32..256 workgroups (one per CU,
-// 512 threads) that stays resident for all lIterations iterations:
-//   * r, delta and the transient Ap live in registers (8 tile slots of 64x4 vertices per half
-//     workgroup, one vertex per lane per slot); M^-1, flags and tile origins in small LDS tables,
+// workgroups empty).  Here every frame of the batch is solved by a GROUP of 64..512 workgroups (256
+// threads, TWO workgroups per CU so one computes while the other waits) that stays resident for all
+// lIterations iterations:
+//   * r, delta, M^-1_A, flags and the transient Ap live in registers (9 tile slots of 64x4 vertices per
+//     workgroup, one vertex per lane per slot),
 //   * the search direction p and cos/sin(A) live in LDS as 66x6 halo'd tiles (the stencil reads
 //     every neighbour from LDS),
 //   * per iteration the group exchanges only (a) two 16-byte partial sums per workgroup (all-gather
@@ -28,34 +29,34 @@
 
 namespace arap {
 
-constexpr int RES_WGS = 256;             // workgroups per launch = CUs of an MI355X, one workgroup per CU
-constexpr int RES_MAX_GROUPS = 8;        // frames in flight per launch: 8, 4, 2 or 1 groups of 32..256 workgroups
-constexpr int RES_THREADS = 512;         // 8 wavefronts: two half-workgroups of 4 (one 64x4 tile each), 2 per SIMD
-constexpr int RES_SLOTS = 8;             // tile slots per half-workgroup (register arrays, fully unrolled)
-constexpr int RES_TILES_PER_WG = 2 * RES_SLOTS;
+constexpr int RES_WGS = 512;             // workgroups per launch: TWO per CU of an MI355X (256 CUs), so that one
+                                         // workgroup computes while its CU-mate (another frame's group) waits
+constexpr int RES_MAX_GROUPS = 8;        // frames in flight per launch: 8, 4, 2 or 1 groups of 64..512 workgroups
+constexpr int RES_THREADS = 256;         // 4 wavefronts = the 4 rows of a 64x4 tile, one per SIMD
+constexpr int RES_SLOTS = 9;             // tile slots per workgroup (register arrays, fully unrolled)
+constexpr int RES_TILES_PER_WG = RES_SLOTS;
 constexpr int RES_MAX_HALO = RES_TILES_PER_WG * 136;                 // 2 x 64 + 2 x 4 halo cells per tile
 constexpr int RES_HALO_PER_THREAD = (RES_MAX_HALO + RES_THREADS - 1) / RES_THREADS;   // 5
-constexpr int RES_MAX_TILES = RES_WGS * RES_TILES_PER_WG;   // 4096 tiles (one group of 256 workgroups)
+constexpr int RES_MAX_TILES = RES_WGS * RES_TILES_PER_WG;   // 4608 tiles (one group of 512 workgroups)
 constexpr int LROW = TILE_X + 2;         // 66
 constexpr int LROWS = TILE_Y + 2;        // 6
 constexpr int LPLANE = LROW * LROWS;     // 396 floats
 constexpr int LTILE = 5 * LPLANE;        // px, py, pa, cos, sin
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
-                              + RES_TILES_PER_WG * 256 * 4      // M^-1 of the Angle component
-                              + RES_TILES_PER_WG * 256          // flag bytes
-                              + RES_MAX_HALO * 2                // halo list
-                              + RES_TILES_PER_WG * 8 + 256;     // tile origins, tables, scratch
+                              + ((RES_MAX_HALO * 2 + 15) / 16) * 16   // halo list
+                              + RES_TILES_PER_WG * 8 + 8 + 256; // tile origins, tables, scratch  (~74 KB: 2 per CU)
 constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
 
 struct ResDev {
     const int* tilelist;        // [batch][RES_MAX_TILES] linear tile index (ty * tilesX + tx) of active tiles
     const int* ntiles;          // [batch]
-    unsigned long long* gran;   // [groups][2 parity][wgs][2]  {tag << 32 | 32 value bits}; groups*wgs = 256
+    unsigned long long* gran;   // [groups][2 parity][wgs][2]  {tag << 32 | 32 value bits}; groups*wgs = RES_WGS
     unsigned* err;              // [1] 0 = ok
     int nframes;                // frames of this launch, <= groups
     int slot0;                  // first batch slot of this launch
     int groups;                 // 8, 4, 2 or 1
-    int wgs;                    // workgroups per group = 256 / groups
+    int wgs;                    // workgroups per group = RES_WGS / groups
+    unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][8] summed s_memrealtime ticks
 };
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -130,8 +131,8 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
     return good;
 }
 
-// block-wide sum of a double over the 8 wavefronts; result valid in wave 0 lane 0
-__device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 8 doubles */)
+// block-wide sum of a double over the 4 wavefronts; result valid in wave 0 lane 0
+__device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 doubles */)
 {
     v = wave_sum(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -145,14 +146,16 @@ __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 8 do
     return t;
 }
 
-// grid = 256 workgroups (groups x wgs), block = 512, dynamic LDS = RES_LDS_BYTES
+// grid = 512 workgroups (groups x wgs), block = 256, dynamic LDS = RES_LDS_BYTES (two workgroups per CU)
 //
-// LDS map: 16 halo'd tiles x {px,py,pa,cos,sin} (126 720 B); M^-1_A [16][256] floats; flag bytes
-// [16][256]; halo list (u16 cell ids, <= 2176); tile origins int2[16]; the 10-entry M^-1_O table;
-// broadcast + reduction scratch.  Registers per lane: r(3) delta(3) Ap(3) for each of 8 slots = 72.
-// Wavefronts 0-3 (half 0) own the even local tiles, wavefronts 4-7 (half 1) the odd ones.
+// LDS map: 9 halo'd tiles x {px,py,pa,cos,sin} (71 280 B); halo list (u16 cell ids, <= 1224); tile
+// origins int2[9]; the 10-entry M^-1_O table; broadcast + reduction scratch.
+// Registers per lane: r(3) delta(3) Ap(3) M^-1_A flags for each of the 9 slots = 99.
+template <bool STAMPS>
 __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, ResDev rd, int L)
 {
+    unsigned long long tA = 0, tS1 = 0, tB = 0, tS2 = 0, tU = 0, t0 = 0, t1 = 0;
+#define RES_STAMP(acc) do { if (STAMPS) { t1 = __builtin_amdgcn_s_memrealtime(); acc += t1 - t0; t0 = t1; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int g = blockIdx.x % rd.groups;              // tends to keep a group on one XCD (speed only)
     const int rank = blockIdx.x / rd.groups;
@@ -162,16 +165,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     const int W = pd.W, H = pd.H;
     const size_t gb = (size_t)b * pd.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = wave >> 2, wy = wave & 3;         // half-workgroup; row inside the tile
-    const int t256 = tid & 255;                        // thread index inside the half = position in the tile
-    float* maT = lds + RES_TILES_PER_WG * LTILE;                          // [16][256]
-    unsigned char* flT = (unsigned char*)(maT + RES_TILES_PER_WG * 256);  // [16][256]
-    unsigned short* hlist = (unsigned short*)(flT + RES_TILES_PER_WG * 256);   // [RES_MAX_HALO]
-    int2* tbase = (int2*)(hlist + RES_MAX_HALO);                          // [16] tile origin (x0, y0) or (-1,-1)
-    float* moLUT = (float*)(tbase + RES_TILES_PER_WG);                    // [10] (+2 pad)
+    const int wy = wave;                               // row inside the tile
+    unsigned short* hlist = (unsigned short*)(lds + RES_TILES_PER_WG * LTILE);    // [RES_MAX_HALO]
+    int2* tbase = (int2*)((char*)hlist + ((RES_MAX_HALO * 2 + 15) / 16) * 16);    // [9] tile origin (x0, y0)
+    float* moLUT = (float*)(tbase + RES_TILES_PER_WG + 1);                // [10] (+2 pad)
     float* bcast = moLUT + 12;                                            // 2 floats + nhalo (int) + pad
     int* nhalo = (int*)(bcast + 2);
-    double* wsum = (double*)(bcast + 4);                                  // 8 doubles
+    double* wsum = (double*)(bcast + 4);                                  // 4 doubles
     unsigned long long* gran_group = rd.gran + (size_t)g * 2 * wgs * 2;
 
     const int nt = rd.ntiles[b];
@@ -197,6 +197,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     float rx[RES_SLOTS], ry[RES_SLOTS], ra[RES_SLOTS];
     float dx_[RES_SLOTS], dy_[RES_SLOTS], da_[RES_SLOTS];
     float apx[RES_SLOTS], apy[RES_SLOTS], apa[RES_SLOTS];
+    float ma_[RES_SLOTS];
+    unsigned fl[RES_SLOTS];
 
     // cell (row, col) of plane k of local tile t : lds[t*LTILE + k*LPLANE + row*LROW + col]
     const int cell = (wy + 1) * LROW + (lane + 1);
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // ---- prologue: load state, p0 and cos/sin with halos ------------------------------------------
 #pragma unroll
     for (int j = 0; j < RES_SLOTS; ++j) {
-        const int k = 2 * j + half;                    // local tile of this half in slot j
+        const int k = j;                               // local tile
         const int gt = rank * tp + k;                  // position in the frame's active-tile list
         rx[j] = ry[j] = ra[j] = 0.f; dx_[j] = dy_[j] = da_[j] = 0.f;
         apx[j] = apy[j] = apa[j] = 0.f;
@@ -247,36 +249,34 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 }
             }
         }
-        flT[k * 256 + t256] = (unsigned char)f;
-        maT[k * 256 + t256] = mA;
-        if (t256 == 0) tbase[k] = make_int2(x0, y0);
+        fl[j] = f;
+        ma_[j] = mA;
+        if (tid == 0) tbase[k] = make_int2(x0, y0);
         __builtin_amdgcn_sched_barrier(0);
     }
     float rho = read_scalar(pd.red + ((size_t)b * pd.nslots + 0) * NSHARD);     // rho_0 from k_gn_init
     __syncthreads();
-    // ---- halo list: every halo cell whose adjacent interior vertex has the matching edge bit ------------
-    // candidate c of tile k: [0,64) top row, [64,128) bottom row, [128,132) left column, [132,136) right
-    for (int c = tid; c < RES_TILES_PER_WG * 136; c += RES_THREADS) {
-        const int k = c / 136, q = c - k * 136;
-        int row, col;
-        unsigned f;
-        if (q < 64) { row = 0; col = q + 1; f = flT[k * 256 + 0 * 64 + q] & F_E3; }
-        else if (q < 128) { row = 5; col = q - 64 + 1; f = flT[k * 256 + 3 * 64 + (q - 64)] & F_E2; }
-        else if (q < 132) { row = q - 128 + 1; col = 0; f = flT[k * 256 + (q - 128) * 64 + 0] & F_E1; }
-        else { row = q - 132 + 1; col = 65; f = flT[k * 256 + (q - 132) * 64 + 63] & F_E0; }
-        if (f) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(k * LPLANE + row * LROW + col);
+    // ---- halo list: every halo cell whose adjacent interior vertex (this lane's) has the matching edge bit
+#pragma unroll
+    for (int j = 0; j < RES_SLOTS; ++j) {
+        const unsigned f = fl[j];
+        if (wy == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lane + 1);
+        if (wy == 3 && (f & F_E2)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 5 * LROW + lane + 1);
+        if (lane == 0 && (f & F_E1)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (wy + 1) * LROW + 0);
+        if (lane == 63 && (f & F_E0)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (wy + 1) * LROW + 65);
     }
     __syncthreads();
     const int nh = *nhalo;
 
     bool alive = true;
+    if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
     for (int l = 0; l < L && alive; ++l) {
         // ---------------- phase A: Ap = J^T J p, sigma = p.Ap --------------------------------------
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < RES_SLOTS; ++j) {
-            const int k = 2 * j + half;
-            const unsigned f = flT[k * 256 + t256];
+            const int k = j;
+            const unsigned f = fl[j];
             if (f & F_ACT) {
                 const float* T = lds + k * LTILE;
                 const float px_ = T[0 * LPLANE + cell], py_ = T[1 * LPLANE + cell], pa_ = T[2 * LPLANE + cell];
@@ -309,20 +309,22 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             __builtin_amdgcn_sched_barrier(0);
         }
         float sigma;
+        RES_STAMP(tA);
         alive = group_sum(block_sum8(acc, wsum), 2u * l + 1u, gran_group, rank, wgs, bcast, rd.err, sigma);
         if (!alive) break;
+        RES_STAMP(tS1);
         // ---------------- phase B: alpha, delta, r, z, rho' -----------------------------------------
         float alpha = 0.f;
         if (sigma > 0.f) alpha = rho / sigma;
         acc = 0.0;
 #pragma unroll
         for (int j = 0; j < RES_SLOTS; ++j) {
-            const int k = 2 * j + half;
-            const unsigned f = flT[k * 256 + t256];
+            const int k = j;
+            const unsigned f = fl[j];
             if (f & F_ACT) {
                 const float* T = lds + k * LTILE;
                 const float px_ = T[0 * LPLANE + cell], py_ = T[1 * LPLANE + cell], pa_ = T[2 * LPLANE + cell];
-                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = maT[k * 256 + t256];
+                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = ma_[j];
                 const int2 tb = tbase[k];
                 const int i = tb.x + lane + W * (tb.y + wy);
                 dx_[j] = dx_[j] + alpha * px_;
@@ -340,8 +342,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains (R1)
         float rhoNew;
+        RES_STAMP(tB);
         alive = group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, rhoNew);
         if (!alive) break;
+        RES_STAMP(tS2);
         float beta = 0.f;
         if (rho > 0.f) beta = rhoNew / rho;
         rho = rhoNew;
@@ -371,11 +375,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         // (2) own cells while those loads fly
 #pragma unroll
         for (int j = 0; j < RES_SLOTS; ++j) {
-            const int k = 2 * j + half;
-            const unsigned f = flT[k * 256 + t256];
+            const int k = j;
+            const unsigned f = fl[j];
             if (f & F_ACT) {
                 float* T = lds + k * LTILE;
-                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = maT[k * 256 + t256];
+                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = ma_[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
                 T[0 * LPLANE + cell] = zx + beta * T[0 * LPLANE + cell];
                 T[1 * LPLANE + cell] = zy + beta * T[1 * LPLANE + cell];
@@ -393,13 +397,18 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             }
         }
         __syncthreads();
+        RES_STAMP(tU);
+    }
+    if (STAMPS && tid == 0) {
+        unsigned long long* o = rd.stamps + (size_t)blockIdx.x * 8;
+        o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; o[6] = (unsigned long long)nh;
     }
     if (!alive) return;
     // ---- epilogue: delta back to the plan images for k_gn_update --------------------------------------
 #pragma unroll
     for (int j = 0; j < RES_SLOTS; ++j) {
-        const int k = 2 * j + half;
-        const unsigned f = flT[k * 256 + t256];
+        const int k = j;
+        const unsigned f = fl[j];
         if (f & F_ACT) {
             const int2 tb = tbase[k];
             const int i = tb.x + lane + W * (tb.y + wy);
@@ -408,5 +417,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
     }
 }
+
+#undef RES_STAMP
 
 }  // namespace arap

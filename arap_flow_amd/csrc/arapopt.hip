@@ -172,12 +172,12 @@ static void plan_enable_resident(Opt_Plan* p)
     if (nr && nr[0] == '1') return;
     hipDeviceProp_t prop;
     HC(hipGetDeviceProperties(&prop, st->device));
-    if (prop.multiProcessorCount < RES_WGS) return;
-    if (hipFuncSetAttribute((const void*)k_pcg_resident, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (prop.multiProcessorCount * 2 < RES_WGS) return;        // two resident workgroups per CU
+    if (hipFuncSetAttribute((const void*)k_pcg_resident<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             RES_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return; }
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pcg_resident, RES_THREADS,
-                                                     RES_LDS_BYTES) != hipSuccess || occ < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pcg_resident<false>, RES_THREADS,
+                                                     RES_LDS_BYTES) != hipSuccess || occ < 2) {
         (void)hipGetLastError();
         return;
     }
@@ -191,6 +191,14 @@ static void plan_enable_resident(Opt_Plan* p)
     p->rd.tilelist = (const int*)c; c += sz_tl;            // exactly this 16-byte-multiple block
     p->rd.ntiles = (const int*)c; c += sz_nt;
     p->rd.err = (unsigned*)c;
+    p->rd.stamps = nullptr;
+    const char* sd = getenv("ARAPOPT_STAMPS");      // diagnostic build of the resident kernel (tools/res_stamps.py)
+    if (sd && sd[0] == '1') {
+        HC(hipFuncSetAttribute((const void*)k_pcg_resident<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               RES_LDS_BYTES));
+        HC(hipMalloc(&p->rd.stamps, RES_WGS * 8 * sizeof(unsigned long long)));
+        HC(hipMemset(p->rd.stamps, 0, RES_WGS * 8 * sizeof(unsigned long long)));
+    }
     p->res_capable = true;
     p->res_frames = true;
 }
@@ -311,7 +319,10 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
             rd.slot0 = s0;
             rd.nframes = p->nb - s0 < rd.groups ? p->nb - s0 : rd.groups;
             HC(hipMemsetAsync(rd.gran, 0, (size_t)2 * RES_WGS * 2 * 8, s));
-            hipLaunchKernelGGL(k_pcg_resident, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
+            if (rd.stamps)
+                hipLaunchKernelGGL(k_pcg_resident<true>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
+            else
+                hipLaunchKernelGGL(k_pcg_resident<false>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
             p->res_launches++;
         }
     } else {
@@ -937,6 +948,15 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg, uint64_t* active, ui
 }
 
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s) { return s ? s->plan->res_launches : 0; }
+
+// diagnostic (ARAPOPT_STAMPS=1): copy the [256][8] phase-time table of the LAST resident launch
+int ArapFlow_SolverStamps(ArapFlow_Solver* s, uint64_t* out)
+{
+    if (!s || !s->plan->rd.stamps) return -1;
+    HC(hipStreamSynchronize(s->st->stream));
+    HC(hipMemcpy(out, s->plan->rd.stamps, RES_WGS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 uint64_t ArapFlow_WarpScratchBytes(unsigned W, unsigned H)
 {

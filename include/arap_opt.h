@@ -184,6 +184,10 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg_iterations_per_frame,
  * ArapFlow_SolverResidentLaunches counts resident launches since the solver was created. */
 void ArapFlow_SetResident(Opt_State* state, int on);
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s);
+/* Diagnostic only (env ARAPOPT_STAMPS=1 selects an instrumented build of the resident kernel): copies
+ * out[512][8] = per workgroup {phase A, wait 1, phase B, wait 2, update} summed 100 MHz ticks of the
+ * last resident launch, tiles per workgroup, halo cells.  Returns -1 when stamps are off. */
+int ArapFlow_SolverStamps(ArapFlow_Solver* s, uint64_t* out);
 
 /* warp_image (ARAP/warping/src/main.cpp:145-225) on DEVICE buffers: rgb uint8[H][W][3], mask_red
  * uint8[H][W], flow float[H][W][2] -> out_rgb uint8[H][W][3], out_mask uint8[H][W].

@@ -1,0 +1,28 @@
+"""Diagnostic: where does a PCG iteration of the resident kernel spend its time?
+   ARAPOPT_STAMPS=1 python tools/res_stamps.py [batch]   (instrumented build; never quote its run time)"""
+import os, sys, time
+os.environ["ARAPOPT_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from arap_flow_amd import opt, synth
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+full = len(sys.argv) > 2 and sys.argv[2] == "full"
+W, H, L = 854, 480, 400
+st = opt.State()
+fs = opt.FrameSolver(st, W, H, batch=B)
+for b in range(B):
+    f = synth.make_frame(W, H, seed=b, full_mask=full)
+    fs.set_frame(b, f["mask_red"], f["constraints"])
+fs.solve(B, 1, 2, L)
+torch.cuda.synchronize()
+t = time.perf_counter(); fs.solve(B, 1, 4, L); torch.cuda.synchronize(); dt = time.perf_counter() - t
+out = np.zeros((512, 8), np.uint64)
+assert st.lib.ArapFlow_SolverStamps(fs.h, out.ctypes.data) == 0
+o = out.astype(np.float64)
+used = o[:, 0] > 0
+us = o[used, :5] * 0.01 / L          # 100 MHz ticks -> us per iteration
+print("frames", B, "wall us/iter (4 GN steps incl. launches):", dt / (4 * L) * 1e6, fs.stats())
+print("workgroups active", used.sum(), "tiles/WG", o[used, 5].min(), o[used, 5].max(), "halo cells", o[used, 6].min(), o[used, 6].max())
+for n, col in zip(["phaseA", "wait1", "phaseB+drain", "wait2", "update"], us.T):
+    print("%-14s mean %.2f  min %.2f  max %.2f us" % (n, col.mean(), col.min(), col.max()))
+print("sum of means %.2f us" % us.mean(0).sum())
