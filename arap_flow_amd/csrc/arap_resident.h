@@ -44,7 +44,7 @@ constexpr int LPLANE = LROW * LROWS;     // 396 floats
 constexpr int LTILE = 5 * LPLANE;        // px, py, pa, cos, sin
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
                               + ((RES_MAX_HALO * 2 + 15) / 16) * 16   // halo list
-                              + RES_TILES_PER_WG * 8 + 8 + 256; // tile origins, tables, scratch  (~74 KB: 2 per CU)
+                              + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (~74 KB: 2 per CU)
 constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
 
 struct ResDev {
@@ -56,6 +56,7 @@ struct ResDev {
     int slot0;                  // first batch slot of this launch
     int groups;                 // 8, 4, 2 or 1
     int wgs;                    // workgroups per group = RES_WGS / groups
+    int allow_fast;             // 0: always use the write-through (placement independent) store flavour
     unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][8] summed s_memrealtime ticks
 };
 
@@ -70,6 +71,18 @@ __device__ __forceinline__ void st_sc1_f2(float2* p, float2 v)
 __device__ __forceinline__ void st_sc1_f(float* p, float v)
 {
     __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Same-XCD fast path: when every workgroup of a group reports the same XCC id (checked at run time, see
+// the kernel), the XCD's L2 is the coherence point for all of them, so handed-off bytes may be written with
+// plain stores (they stay in that L2 instead of being written through to memory) and are still read with
+// sc1 loads (which bypass the reader's L1 and are served by that same L2).
+__device__ __forceinline__ void st_pub_f2(float2* p, float2 v, bool fast)
+{
+    if (fast) *p = v; else st_sc1_f2(p, v);
+}
+__device__ __forceinline__ void st_pub_f(float* p, float v, bool fast)
+{
+    if (fast) *p = v; else st_sc1_f(p, v);
 }
 __device__ __forceinline__ float2 ld_sc1_f2(const float2* p)
 {
@@ -88,7 +101,8 @@ __device__ __forceinline__ float ld_sc1_f(const float* p)
 // then a fixed xor-butterfly adds the lanes, so every workgroup of the group computes the same bits.
 // Returns the sum rounded to float in every thread; false on timeout.
 __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned long long* gran_group, int rank,
-                                          int wgs, float* bcast /* LDS, 2 floats */, unsigned* err, float& out)
+                                          int wgs, float* bcast /* LDS, 2 floats */, unsigned* err, float& out,
+                                          bool fast = false, double* out_d = nullptr)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
@@ -97,8 +111,11 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
         if (lane < 2) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(part);
             const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
-            __hip_atomic_store(buf + rank * 2 + lane, ((unsigned long long)epoch << 32) | hw, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long gv = ((unsigned long long)epoch << 32) | hw;
+            if (fast)
+                __hip_atomic_store(buf + rank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else
+                __hip_atomic_store(buf + rank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         double v = 0.0;
         bool ok = false;
@@ -120,6 +137,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
         if (lane == 0) {
             bcast[0] = (float)v;
+            if (out_d) *out_d = v;         // LDS double, read by the caller after the barrier below
             bcast[1] = ok ? 1.0f : 0.0f;
             if (!ok) atomicExch(err, 0xDEAD0000u | (epoch & 0xffffu));
         }
@@ -269,6 +287,20 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     const int nh = *nhalo;
 
     bool alive = true;
+    // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------
+    // every workgroup publishes xcc + 65536 xcc^2 through the placement-independent protocol (epoch 1);
+    // the ids are all equal iff  wgs * sum(xcc^2) == (sum xcc)^2.
+    bool fast = false;
+    {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // HW_REG_XCC_ID
+        float dummy;
+        const double mine = (double)xcc + 65536.0 * (double)(xcc * xcc);
+        alive = group_sum(mine, 1u, gran_group, rank, wgs, bcast, rd.err, dummy, false, wsum + 8);
+        const double tot = wsum[8];
+        const double s2 = floor(tot / 65536.0), s1 = tot - 65536.0 * s2;
+        fast = rd.allow_fast && ((double)wgs * s2 == s1 * s1);
+        __syncthreads();
+    }
     if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
     for (int l = 0; l < L && alive; ++l) {
         // ---------------- phase A: Ap = J^T J p, sigma = p.Ap --------------------------------------
@@ -310,7 +342,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
         float sigma;
         RES_STAMP(tA);
-        alive = group_sum(block_sum8(acc, wsum), 2u * l + 1u, gran_group, rank, wgs, bcast, rd.err, sigma);
+        alive = group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast);
         if (!alive) break;
         RES_STAMP(tS1);
         // ---------------- phase B: alpha, delta, r, z, rho' -----------------------------------------
@@ -334,8 +366,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 ry[j] = ry[j] - alpha * apy[j];
                 ra[j] = ra[j] - alpha * apa[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-                st_sc1_f2(pd.zO + gb + i, make_float2(zx, zy));
-                st_sc1_f(pd.zA + gb + i, za);
+                st_pub_f2(pd.zO + gb + i, make_float2(zx, zy), fast);
+                st_pub_f(pd.zA + gb + i, za, fast);
                 acc += (double)dot3(zx, zy, za, rx[j], ry[j], ra[j]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -343,7 +375,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains (R1)
         float rhoNew;
         RES_STAMP(tB);
-        alive = group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, rhoNew);
+        alive = group_sum(block_sum8(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast);
         if (!alive) break;
         RES_STAMP(tS2);
         float beta = 0.f;
@@ -401,7 +433,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     if (STAMPS && tid == 0) {
         unsigned long long* o = rd.stamps + (size_t)blockIdx.x * 8;
-        o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; o[6] = (unsigned long long)nh;
+        o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; o[6] = (unsigned long long)nh; o[7] = fast ? 1ull : 0ull;
     }
     if (!alive) return;
     // ---- epilogue: delta back to the plan images for k_gn_update --------------------------------------

@@ -192,6 +192,10 @@ static void plan_enable_resident(Opt_Plan* p)
     p->rd.ntiles = (const int*)c; c += sz_nt;
     p->rd.err = (unsigned*)c;
     p->rd.stamps = nullptr;
+    {
+        const char* nf = getenv("ARAPOPT_NO_XCD_FAST");
+        p->rd.allow_fast = (nf && nf[0] == '1') ? 0 : 1;
+    }
     const char* sd = getenv("ARAPOPT_STAMPS");      // diagnostic build of the resident kernel (tools/res_stamps.py)
     if (sd && sd[0] == '1') {
         HC(hipFuncSetAttribute((const void*)k_pcg_resident<true>, hipFuncAttributeMaxDynamicSharedMemorySize,

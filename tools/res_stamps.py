@@ -22,6 +22,7 @@ o = out.astype(np.float64)
 used = o[:, 0] > 0
 us = o[used, :5] * 0.01 / L          # 100 MHz ticks -> us per iteration
 print("frames", B, "wall us/iter (4 GN steps incl. launches):", dt / (4 * L) * 1e6, fs.stats())
+print("same-XCD fast path in", int(o[used, 7].sum()), "of", int(used.sum()), "workgroups")
 print("workgroups active", used.sum(), "tiles/WG", o[used, 5].min(), o[used, 5].max(), "halo cells", o[used, 6].min(), o[used, 6].max())
 for n, col in zip(["phaseA", "wait1", "phaseB+drain", "wait2", "update"], us.T):
     print("%-14s mean %.2f  min %.2f  max %.2f us" % (n, col.mean(), col.min(), col.max()))
