@@ -3,6 +3,8 @@
 hipcc cross-compiles without a GPU.  Flags that matter for results:
   -ffp-contract=off     every float operator is one IEEE operation (parity tier T3)
   -munsafe-fp-atomics   float64 atomic add is the hardware global_atomic_add_f64, not a CAS loop
+  -fno-slp-vectorize    the SLP vectoriser pairs unrelated scalars of the resident kernel's register arrays and
+                        spills ~300 VGPRs; packed-f32 math is written explicitly on float2 instead
 """
 import os
 import subprocess
@@ -16,7 +18,7 @@ OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libarapopt.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+         "-munsafe-fp-atomics", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def up_to_date():

@@ -41,7 +41,7 @@ constexpr int RES_MAX_TILES = RES_WGS * RES_TILES_PER_WG;   // 4608 tiles (one g
 constexpr int LROW = TILE_X + 2;         // 66
 constexpr int LROWS = TILE_Y + 2;        // 6
 constexpr int LPLANE = LROW * LROWS;     // 396 floats
-constexpr int LTILE = 5 * LPLANE;        // px, py, pa, cos, sin
+constexpr int LTILE = 5 * LPLANE;        // float2 (px,py) plane | float2 (cos,sin) plane | float pa plane
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
                               + ((RES_MAX_HALO * 2 + 15) / 16) * 16   // halo list
                               + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (~74 KB: 2 per CU)
@@ -218,8 +218,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     float ma_[RES_SLOTS];
     unsigned fl[RES_SLOTS];
 
-    // cell (row, col) of plane k of local tile t : lds[t*LTILE + k*LPLANE + row*LROW + col]
+    // LDS tile t: float2 P2[396] (px,py) | float2 CS[396] (cos,sin) | float PA[396]; cell = row*66 + col
     const int cell = (wy + 1) * LROW + (lane + 1);
+#define TP2(T) ((float2*)(T))
+#define TCS(T) ((float2*)(T) + LPLANE)
+#define TPA(T) ((T) + 4 * LPLANE)
 
     // ---- prologue: load state, p0 and cos/sin with halos ------------------------------------------
 #pragma unroll
@@ -240,9 +243,9 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             if (x < W && y < H) {
                 const int i = x + W * y;
                 f = pd.flags[gb + i];
-                const float2 p0 = pd.pO0[gb + i], cs = pd.cs[gb + i];
-                T[0 * LPLANE + cell] = p0.x; T[1 * LPLANE + cell] = p0.y; T[2 * LPLANE + cell] = pd.pA0[gb + i];
-                T[3 * LPLANE + cell] = cs.x; T[4 * LPLANE + cell] = cs.y;
+                TP2(T)[cell] = pd.pO0[gb + i];
+                TCS(T)[cell] = pd.cs[gb + i];
+                TPA(T)[cell] = pd.pA0[gb + i];
                 if (f & F_ACT) {
                     const float2 r = pd.rO[gb + i];
                     rx[j] = r.x; ry[j] = r.y; ra[j] = pd.rA[gb + i];
@@ -253,17 +256,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 if (wy == 0 && y0 > 0) { hi = i - W; hc = 0 * LROW + (lane + 1); }
                 if (wy == 3 && y + 1 < H) { hi = i + W; hc = 5 * LROW + (lane + 1); }
                 if (hi >= 0) {
-                    const float2 hp = pd.pO0[gb + hi], hcs = pd.cs[gb + hi];
-                    T[0 * LPLANE + hc] = hp.x; T[1 * LPLANE + hc] = hp.y; T[2 * LPLANE + hc] = pd.pA0[gb + hi];
-                    T[3 * LPLANE + hc] = hcs.x; T[4 * LPLANE + hc] = hcs.y;
+                    TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
                 }
                 hi = -1;
                 if (lane == 0 && x0 > 0) { hi = i - 1; hc = (wy + 1) * LROW + 0; }
                 if (lane == 63 && x + 1 < W) { hi = i + 1; hc = (wy + 1) * LROW + 65; }
                 if (hi >= 0) {
-                    const float2 hp = pd.pO0[gb + hi], hcs = pd.cs[gb + hi];
-                    T[0 * LPLANE + hc] = hp.x; T[1 * LPLANE + hc] = hp.y; T[2 * LPLANE + hc] = pd.pA0[gb + hi];
-                    T[3 * LPLANE + hc] = hcs.x; T[4 * LPLANE + hc] = hcs.y;
+                    TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
                 }
             }
         }
@@ -311,32 +310,68 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             const unsigned f = fl[j];
             if (f & F_ACT) {
                 const float* T = lds + k * LTILE;
-                const float px_ = T[0 * LPLANE + cell], py_ = T[1 * LPLANE + cell], pa_ = T[2 * LPLANE + cell];
-                const float ci = T[3 * LPLANE + cell], si = T[4 * LPLANE + cell];
-                float ax = 0.f, ay = 0.f, aa = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if (!(f & (1u << s))) continue;
-                    const int nc = cell + (s == 0 ? 1 : (s == 1 ? -1 : (s == 2 ? LROW : -LROW)));
-                    const float qOx = T[0 * LPLANE + nc], qOy = T[1 * LPLANE + nc], qA = T[2 * LPLANE + nc];
-                    const float cn = T[3 * LPLANE + nc], sn = T[4 * LPLANE + nc];
-                    // d = U(c) - U(n) on the pixel grid
-                    const float dx = s == 0 ? -1.f : (s == 1 ? 1.f : 0.f);
-                    const float dy = s == 2 ? -1.f : (s == 3 ? 1.f : 0.f);
-                    const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
-                    const float hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;
-                    const float ex = px_ - qOx, ey = py_ - qOy;
-                    const float tx = ex - qx * pa_, ty = ey - qy * pa_;
-                    ax = ax + wr2 * ((ex + tx) - hx * qA);
-                    ay = ay + wr2 * ((ey + ty) - hy * qA);
-                    aa = aa - wr2 * (qx * tx + qy * ty);
+                const float2 pv = TP2(T)[cell];
+                const float2 csv = TCS(T)[cell];                 // (ci, si)
+                const float pa_ = TPA(T)[cell];
+                const float2 scv = make_float2(csv.y, csv.x);    // (si, ci)
+                const float2 a0 = make_float2(csv.y * pa_, -(csv.x * pa_));   // ( sp, -cp) = q pa for s=0
+                const float2 a2 = make_float2(csv.x * pa_, csv.y * pa_);      // ( cp,  sp) = q pa for s=2
+                float2 axy = make_float2(0.f, 0.f);
+                float aa = 0.f;
+                // One block per stencil edge, written on (x,y) pairs so that they lower to packed-f32 ops.
+                // On the pixel grid d = U(c)-U(n) = -s, so q = R'(A(c))d and h = R'(A(n))d are signed copies
+                // of (si,ci) / (sn,cn); products with -1/0/1, adding a zero, x-(-y) = x+y and
+                // (-a)+(-b) = -(a+b) are exact, so each block equals the generic k_pcg_a expression
+                //   t = dP - q pa ; a_xy += wr2((e+t) - h qA) ; aa -= wr2(qx tx + qy ty)
+                // value for value (only the sign of an exact zero may differ).
+                if (f & F_E0) {   // s=(1,0): d=(-1,0)  q=( si,-ci)  h=( sn,-cn)
+                    const int nc = cell + 1;
+                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
+                    const float qA = TPA(T)[nc];
+                    const float2 e = pv - qO;
+                    const float2 t = e - a0;
+                    const float2 hq = make_float2(cn2.y * qA, -(cn2.x * qA));
+                    axy = axy + wr2 * ((e + t) - hq);
+                    const float2 m = scv * t;                    // (si tx, ci ty)
+                    aa = aa - wr2 * (m.x - m.y);
                 }
-                if (f & F_FIT) {
-                    ax = ax + wf2 * px_;
-                    ay = ay + wf2 * py_;
+                if (f & F_E1) {   // s=(-1,0): d=(1,0)  q=(-si, ci)  h=(-sn, cn)
+                    const int nc = cell - 1;
+                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
+                    const float qA = TPA(T)[nc];
+                    const float2 e = pv - qO;
+                    const float2 t = e + a0;
+                    const float2 hq = make_float2(cn2.y * qA, -(cn2.x * qA));
+                    axy = axy + wr2 * ((e + t) + hq);
+                    const float2 m = scv * t;
+                    aa = aa - wr2 * (m.y - m.x);
                 }
+                if (f & F_E2) {   // s=(0,1): d=(0,-1)  q=( ci, si)  h=( cn, sn)
+                    const int nc = cell + LROW;
+                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
+                    const float qA = TPA(T)[nc];
+                    const float2 e = pv - qO;
+                    const float2 t = e - a2;
+                    const float2 hq = cn2 * qA;
+                    axy = axy + wr2 * ((e + t) - hq);
+                    const float2 m = csv * t;                    // (ci tx, si ty)
+                    aa = aa - wr2 * (m.x + m.y);
+                }
+                if (f & F_E3) {   // s=(0,-1): d=(0,1)  q=(-ci,-si)  h=(-cn,-sn)
+                    const int nc = cell - LROW;
+                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
+                    const float qA = TPA(T)[nc];
+                    const float2 e = pv - qO;
+                    const float2 t = e + a2;
+                    const float2 hq = cn2 * qA;
+                    axy = axy + wr2 * ((e + t) + hq);
+                    const float2 m = csv * t;
+                    aa = aa + wr2 * (m.x + m.y);
+                }
+                if (f & F_FIT) axy = axy + wf2 * pv;
+                const float ax = axy.x, ay = axy.y;
                 apx[j] = ax; apy[j] = ay; apa[j] = aa;
-                acc += (double)dot3(px_, py_, pa_, ax, ay, aa);
+                acc += (double)dot3(pv.x, pv.y, pa_, ax, ay, aa);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -355,12 +390,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             const unsigned f = fl[j];
             if (f & F_ACT) {
                 const float* T = lds + k * LTILE;
-                const float px_ = T[0 * LPLANE + cell], py_ = T[1 * LPLANE + cell], pa_ = T[2 * LPLANE + cell];
+                const float2 pv = TP2(T)[cell];
+                const float pa_ = TPA(T)[cell];
                 const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = ma_[j];
                 const int2 tb = tbase[k];
                 const int i = tb.x + lane + W * (tb.y + wy);
-                dx_[j] = dx_[j] + alpha * px_;
-                dy_[j] = dy_[j] + alpha * py_;
+                dx_[j] = dx_[j] + alpha * pv.x;
+                dy_[j] = dy_[j] + alpha * pv.y;
                 da_[j] = da_[j] + alpha * pa_;
                 rx[j] = rx[j] - alpha * apx[j];
                 ry[j] = ry[j] - alpha * apy[j];
@@ -399,7 +435,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const int row = rem / LROW, col = rem - row * LROW;
                 const int2 tb = tbase[k];
                 const int hi = (tb.x + col - 1) + W * (tb.y + row - 1);
-                hcell[u] = k * LTILE + rem;
+                hcell[u] = id;
                 hz2[u] = ld_sc1_f2(pd.zO + gb + hi);
                 hz1[u] = ld_sc1_f(pd.zA + gb + hi);
             }
@@ -413,19 +449,20 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 float* T = lds + k * LTILE;
                 const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = ma_[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-                T[0 * LPLANE + cell] = zx + beta * T[0 * LPLANE + cell];
-                T[1 * LPLANE + cell] = zy + beta * T[1 * LPLANE + cell];
-                T[2 * LPLANE + cell] = za + beta * T[2 * LPLANE + cell];
+                const float2 po = TP2(T)[cell];
+                TP2(T)[cell] = make_float2(zx + beta * po.x, zy + beta * po.y);
+                TPA(T)[cell] = za + beta * TPA(T)[cell];
             }
         }
         // (3) halo cells: p_halo = z_halo + beta p_halo (the owner computes the same expression)
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
             if (hcell[u] >= 0) {
-                float* Tc = lds + hcell[u];
-                Tc[0 * LPLANE] = hz2[u].x + beta * Tc[0 * LPLANE];
-                Tc[1 * LPLANE] = hz2[u].y + beta * Tc[1 * LPLANE];
-                Tc[2 * LPLANE] = hz1[u] + beta * Tc[2 * LPLANE];
+                const int k = hcell[u] / LPLANE, rem = hcell[u] - k * LPLANE;
+                float* T = lds + k * LTILE;
+                const float2 po = TP2(T)[rem];
+                TP2(T)[rem] = make_float2(hz2[u].x + beta * po.x, hz2[u].y + beta * po.y);
+                TPA(T)[rem] = hz1[u] + beta * TPA(T)[rem];
             }
         }
         __syncthreads();
@@ -451,5 +488,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 }
 
 #undef RES_STAMP
+#undef TP2
+#undef TCS
+#undef TPA
 
 }  // namespace arap
