@@ -209,7 +209,7 @@ static void plan_enable_resident(Opt_Plan* p)
 
 static bool plan_resident_eligible(const Opt_Plan* p)
 {
-    if (!p->res_capable || !p->res_frames || p->st->timing || !p->st->use_resident) return false;
+    if (!p->res_capable || !p->res_frames || !p->st->use_resident) return false;
     for (int b = 0; b < p->nb; ++b)
         if (p->h_ntiles[b] > RES_MAX_TILES) return false;
     return true;
@@ -304,6 +304,21 @@ static void plan_upload_slots(Opt_Plan* p)
         }                                                                                   \
     } while (0)
 
+#define LAUNCH_DYN(p, st_, kname_, kern, grid, blk, lds_, ...)                               \
+    do {                                                                                    \
+        if ((p)->st->timing) {                                                              \
+            KernelTimer::Rec r_;                                                            \
+            r_.name = kname_;                                                               \
+            HC(hipEventCreate(&r_.a)); HC(hipEventCreate(&r_.b));                           \
+            HC(hipEventRecord(r_.a, st_));                                                  \
+            hipLaunchKernelGGL(kern, grid, blk, lds_, st_, __VA_ARGS__);                    \
+            HC(hipEventRecord(r_.b, st_));                                                  \
+            (p)->st->ktimer.recs.push_back(r_);                                             \
+        } else {                                                                            \
+            hipLaunchKernelGGL(kern, grid, blk, lds_, st_, __VA_ARGS__);                    \
+        }                                                                                   \
+    } while (0)
+
 // enqueue the kernels of one Gauss-Newton step (without the cost) on stream s
 static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
 {
@@ -326,7 +341,8 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
             if (rd.stamps)
                 hipLaunchKernelGGL(k_pcg_resident<true>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
             else
-                hipLaunchKernelGGL(k_pcg_resident<false>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
+                LAUNCH_DYN(p, s, "PCGResident", k_pcg_resident<false>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES,
+                           p->pd, rd, L);
             p->res_launches++;
         }
     } else {
