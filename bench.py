@@ -80,15 +80,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from arap_flow_amd import opt, synth
+    from arap_flow_amd import opt, shard, synth
 
     W, H = a.size
     B = a.batch
     numIter, nIter, lIter = a.schedule
     st = opt.State()
     fs = opt.FrameSolver(st, W, H, batch=B)
-    frames = [synth.make_frame(W, H, seed=rank * B + b, K=1, fd=1, full_mask=(a.workload == "full"))
-              for b in range(B)]
+    # the job's frame list (world x B frames per step) is dealt round-robin to the ranks: no collective
+    seeds = shard.shard_indices(world * B, rank, world)
+    frames = [synth.make_frame(W, H, seed=sd, K=1, fd=1, full_mask=(a.workload == "full")) for sd in seeds]
     for b, f in enumerate(frames):
         fs.set_frame(b, f["mask_red"], f["constraints"], rgb=f["rgb"])
     torch.cuda.synchronize()
@@ -113,10 +114,7 @@ def main():
     ev_ms = st.timer_end()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, dist, device="cuda")
     stats = fs.stats()
     total_frames = world * B * a.steps
     fps = total_frames / dt

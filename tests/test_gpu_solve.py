@@ -186,3 +186,54 @@ def test_resident_and_two_kernel_paths_are_bit_identical(gpu_state):
         for a, b in zip(*outs):
             assert np.array_equal(a["offset"], b["offset"]) and np.array_equal(a["angle"], b["angle"])
             assert a["cost"] == b["cost"]
+
+
+@pytest.mark.parametrize("case", ["synth160x96", "cat512"])
+def test_T3_full_schedule_deterministic_twin(gpu_state, oracle, golden_dir, case):
+    """Tier T3: the full 19/8/400 schedule, HIP vs the float32 CPU oracle that performs the same operation
+    list (dot products accumulated in float64, spec cos/sin).  SURVEY 8c asks for 1e-4 "if reachable";
+    measured: 0 differing floats (tools/dbg_t3.py), so the test demands 1e-6 and reports bit equality."""
+    from arap_flow_amd import synth
+    if case == "cat512":
+        cat = helpers.load_cat512(golden_dir)
+        mask, cons = cat["mask_red"], cat["constraints"]
+    else:
+        f = synth.make_frame(160, 96, seed=3, K=1, fd=2)
+        mask, cons = f["mask_red"], f["constraints"]
+    H, W = mask.shape
+    fs = opt.FrameSolver(gpu_state, W, H, batch=1)
+    fs.set_frame(0, mask, cons)
+    fs.solve(1, 19, 8, 400)
+    r = fs.results(0, want_rgb=False)
+    fs.close()
+    O, A, costs = oracle.frame(mask, cons, dtype=np.float32, mode=1, trig=1)
+    ys, xs = np.mgrid[0:H, 0:W]
+    grid = np.stack([xs, ys], -1).astype(np.float32)
+    assert helpers.rel_l2(r["offset"] - grid, O - grid) < 1e-6
+    assert helpers.rel_l2(r["angle"], A) < 1e-6
+    assert abs(r["cost"] - costs[-1]) <= 1e-6 * costs[-1]
+    print("T3 %s: differing floats Offset %d Angle %d" % (case, int((r["offset"] != O).sum()), int((r["angle"] != A).sum())))
+
+
+def test_multseg_segments_batched_equal_separate_solves(gpu_state):
+    """--multseg (para_gen.py:518-540): each label of a frame is its own ARAP solve; batching the segment
+    solves of one frame on one GPU (BASELINE config 3) must equal solving them one at a time."""
+    from arap_flow_amd import synth
+    W, H = 214, 120
+    frame = synth.make_frame(W, H, seed=21, K=3, fd=2)
+    segs = synth.segment_masks(frame)
+    sched = (2, 2, 50)
+    fs = opt.FrameSolver(gpu_state, W, H, batch=len(segs))
+    for b, s in enumerate(segs):
+        fs.set_frame(b, s["mask_red"], s["constraints"])
+    fs.solve(len(segs), *sched)
+    together = [fs.results(b, want_rgb=False) for b in range(len(segs))]
+    fs.close()
+    for b, s in enumerate(segs):
+        one = opt.FrameSolver(gpu_state, W, H, batch=1)
+        one.set_frame(0, s["mask_red"], s["constraints"])
+        one.solve(1, *sched)
+        r = one.results(0, want_rgb=False)
+        one.close()
+        assert np.array_equal(r["offset"], together[b]["offset"]) and np.array_equal(r["angle"], together[b]["angle"])
+        assert np.all(together[b]["flow"][s["mask_red"] != 0] == 0)
