@@ -1,0 +1,91 @@
+"""GPU: the command-line twins end to end (child processes, as the reference's para_gen.py runs its binaries)."""
+import os
+import os.path as osp
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from PIL import Image
+
+import helpers
+from arap_flow_amd import flo, opt, pipeline, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = osp.dirname(osp.dirname(osp.abspath(__file__)))
+
+
+def _run(args, cwd):
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", "0"))
+    r = subprocess.run([sys.executable] + args, cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+def test_warp_image_cli_reproduces_reference_fixture(tmp_path, golden_dir):
+    d = osp.join(golden_dir, "cat512")
+    out = _run([osp.join(ROOT, "warp_image.py"), osp.join(d, "cat512_iRGB.png"), osp.join(d, "cat512_iMsk.png"),
+                osp.join(d, "cat512_iFlo.flo"), str(tmp_path / "o.png"), str(tmp_path / "om.png")], str(tmp_path))
+    assert "Saved" in out
+    cat = helpers.load_cat512(golden_dir)
+    wm = np.array(Image.open(tmp_path / "om.png").convert("L"))
+    assert np.array_equal(wm, cat["golden_wmsk"])
+    diff = np.abs(np.array(Image.open(tmp_path / "o.png").convert("RGB")).astype(int) - cat["golden_wrgb"].astype(int))
+    assert diff.max() <= 1
+    bad = subprocess.run([sys.executable, osp.join(ROOT, "warp_image.py"), "a", "b"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Invalid Input!" in bad.stdout
+
+
+def test_arap_deform_cli_list_and_single(tmp_path, gpu_state):
+    """list-file mode (two sizes in one list -> plan rebuilt) and 6-argument mode; output equals the library"""
+    frames = [synth.make_frame(96, 64, seed=1), synth.make_frame(96, 64, seed=2), synth.make_frame(80, 48, seed=3)]
+    lines = []
+    for k, f in enumerate(frames):
+        Image.fromarray(f["rgb"]).save(tmp_path / ("r%d.png" % k))
+        Image.fromarray(np.stack([f["mask_red"]] * 3, -1)).save(tmp_path / ("m%d.png" % k))
+        pipeline.write_constraints(str(tmp_path / ("c%d.txt" % k)), [tuple(c) for c in f["constraints"]])
+        lines.append(" ".join(str(tmp_path / (n % k)) for n in ("r%d.png", "m%d.png", "c%d.txt", "f%d.flo", "w%d.png", "wm%d.png")))
+    (tmp_path / "list.txt").write_text("\n".join(lines))
+    out = _run([osp.join(ROOT, "arap_deform.py"), str(tmp_path / "list.txt")], str(tmp_path))
+    assert out.count("Saved") == 3
+    fs = opt.FrameSolver(gpu_state, 96, 64, batch=1)
+    fs.set_frame(0, frames[1]["mask_red"], frames[1]["constraints"], rgb=frames[1]["rgb"])
+    fs.solve(1, 19, 8, 400); fs.warp(1)
+    r = fs.results(0); fs.close()
+    assert np.array_equal(flo.flow_read(str(tmp_path / "f1.flo")), r["flow"])
+    assert np.array_equal(np.array(Image.open(tmp_path / "w1.png")), r["warped_rgb"])
+    assert np.array_equal(np.array(Image.open(tmp_path / "wm1.png")), r["warped_mask"] > 0)
+    assert flo.flow_read(str(tmp_path / "f2.flo")).shape == (48, 80, 2)
+    single = [str(tmp_path / n) for n in ("r0.png", "m0.png", "c0.txt", "s.flo", "s.png", "sm.png")]
+    _run([osp.join(ROOT, "arap_deform.py")] + single, str(tmp_path))
+    assert np.array_equal(flo.flow_read(single[3]), flo.flow_read(str(tmp_path / "f0.flo")))
+    bad = subprocess.run([sys.executable, osp.join(ROOT, "arap_deform.py")], capture_output=True, text=True)
+    assert bad.returncode == 1 and "Invalid Input!" in bad.stdout
+
+
+@pytest.mark.parametrize("multseg", [False, True])
+def test_para_gen_end_to_end(tmp_path, multseg):
+    """tiny DAVIS-shaped tree -> para_gen.py --gpu 0 [--multseg]: outputs, all_files.list, flatten"""
+    W, H = 96, 64
+    inp, outp, mdir = tmp_path / "in", tmp_path / "out", tmp_path / "matches"
+    for seq in ("a", "b"):
+        os.makedirs(inp / "orgRGB" / seq); os.makedirs(inp / "orgMasks" / seq); os.makedirs(mdir / seq)
+        fr = synth.make_frame(W, H, seed=len(seq) + ord(seq), K=2, fd=1)
+        for n in range(3):
+            Image.fromarray(fr["rgb"]).save(inp / "orgRGB" / seq / ("%05d.png" % n))
+            Image.fromarray(fr["labels"].astype(np.uint8)).save(inp / "orgMasks" / seq / ("%05d.png" % n))
+            (mdir / seq / ("%05d.txt" % n)).write_text("\n".join("%d %d %d %d 1.0 0" % tuple(c) for c in fr["constraints"]))
+    args = [osp.join(ROOT, "para_gen.py"), "--input", str(inp), "--output", str(outp), "--gpu", "0", "--fd", "1",
+            "--matches", str(mdir)] + (["--multseg"] if multseg else [])
+    _run(args, str(tmp_path))
+    lst = open(outp / "all_files.list").read().splitlines()
+    assert len(lst) == 4                                              # 2 sequences x (3 - fd) pairs
+    for ln in lst:
+        rgb1, rgb2, fl = ln.split(" ")
+        f = flo.flow_read(fl)
+        assert f.shape == (H, W, 2) and np.abs(f).max() > 0.5
+        assert np.array(Image.open(rgb2)).shape == (H, W, 3)
+    wm = np.array(Image.open(str(outp / "wMasks" / "a" / "00000.png")))
+    lab = np.array(Image.open(inp / "orgMasks" / "a" / "00000.png"))
+    assert abs(int((wm != 0).sum()) - int((lab != 0).sum())) < 0.2 * (lab != 0).sum()
+    assert not [f for f in os.listdir(outp / "Flow" / "a") if "_seg" in f]          # flattened and removed
