@@ -31,7 +31,7 @@ namespace arap {
 
 constexpr int RES_WGS = 512;             // workgroups per launch: TWO per CU of an MI355X (256 CUs), so that one
                                          // workgroup computes while its CU-mate (another frame's group) waits
-constexpr int RES_MAX_GROUPS = 8;        // frames in flight per launch: 8, 4, 2 or 1 groups of 64..512 workgroups
+constexpr int RES_MAX_GROUPS = 16;       // frames in flight per launch: 16, 8, 4, 2 or 1 groups of 32..512 workgroups
 constexpr int RES_THREADS = 256;         // 4 wavefronts = the 4 rows of a 64x4 tile, one per SIMD
 constexpr int RES_SLOTS = 9;             // tile slots per workgroup (register arrays, fully unrolled)
 constexpr int RES_TILES_PER_WG = RES_SLOTS;
@@ -54,7 +54,7 @@ struct ResDev {
     unsigned* err;              // [1] 0 = ok
     int nframes;                // frames of this launch, <= groups
     int slot0;                  // first batch slot of this launch
-    int groups;                 // 8, 4, 2 or 1
+    int groups;                 // 16, 8, 4, 2 or 1
     int wgs;                    // workgroups per group = RES_WGS / groups
     int allow_fast;             // 0: always use the write-through (placement independent) store flavour
     unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][8] summed s_memrealtime ticks
@@ -175,8 +175,19 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     unsigned long long tA = 0, tS1 = 0, tB = 0, tS2 = 0, tU = 0, t0 = 0, t1 = 0;
 #define RES_STAMP(acc) do { if (STAMPS) { t1 = __builtin_amdgcn_s_memrealtime(); acc += t1 - t0; t0 = t1; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int g = blockIdx.x % rd.groups;              // tends to keep a group on one XCD (speed only)
-    const int rank = blockIdx.x / rd.groups;
+    // Group of this workgroup.  Speed only (never correctness): workgroups are dealt round-robin over the 8
+    // XCDs, so blockIdx & 7 labels the XCD.  With >= 8 groups a group is the j-th block of `wgs` workgroups of
+    // one XCD: it stays on that XCD (same-XCD fast path) and, with 16 groups, the two workgroups that share a CU
+    // (local indices j and j + 32) belong to different frames, so one computes while the other waits.
+    int g, rank;
+    if (rd.groups >= 8) {
+        const int j = blockIdx.x >> 3;
+        g = (blockIdx.x & 7) + 8 * (j / rd.wgs);
+        rank = j % rd.wgs;
+    } else {
+        g = blockIdx.x % rd.groups;
+        rank = blockIdx.x / rd.groups;
+    }
     if (g >= rd.nframes) return;                       // whole groups leave together
     const int b = rd.slot0 + g;
     const int wgs = rd.wgs;

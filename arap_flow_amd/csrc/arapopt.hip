@@ -222,7 +222,10 @@ static int plan_resident_groups(const Opt_Plan* p)
     for (int b = 0; b < p->nb; ++b) mx = p->h_ntiles[b] > mx ? p->h_ntiles[b] : mx;
     int groups = RES_MAX_GROUPS;
     while (groups > 1 && (RES_WGS / groups) * RES_TILES_PER_WG < mx) groups >>= 1;
-    while (groups > 1 && groups / 2 >= p->nb) groups >>= 1;      // fewer frames than groups: widen the groups
+    // Fewer frames than groups: narrow groups still win (a 64-workgroup group sits on one XCD and takes the
+    // same-XCD fast path; a wide group spans XCDs and pays write-through publishing), so do not widen.
+    const char* fg = getenv("ARAPOPT_RES_GROUPS");               // experiments only
+    if (fg && atoi(fg) > 0 && atoi(fg) <= groups) groups = atoi(fg);
     return groups;
 }
 

@@ -40,6 +40,10 @@ def parse():
     ap.add_argument("--schedule", type=int, nargs=3, default=[19, 8, 400], metavar=("NUMITER", "NITER", "LITER"))
     ap.add_argument("--workload", choices=["davis", "full"], default="davis",
                     help="davis: configs[1] single-segment mask (~25%% active); full: mask == 0 (roofline config)")
+    ap.add_argument("--multseg", type=int, default=0, metavar="K",
+                    help="configs[2]/[4]: K segments per frame, each its own ARAP solve (para_gen.py --multseg); "
+                         "--batch then counts frames, K x batch solves run per step")
+    ap.add_argument("--fd", type=int, default=1, help="frame distance of the synthetic matches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -86,17 +90,21 @@ def main():
     B = a.batch
     numIter, nIter, lIter = a.schedule
     st = opt.State()
-    fs = opt.FrameSolver(st, W, H, batch=B)
+    K = max(1, a.multseg)
+    S = B * K                                    # solves per step on this rank
+    fs = opt.FrameSolver(st, W, H, batch=S)
     # the job's frame list (world x B frames per step) is dealt round-robin to the ranks: no collective
     seeds = shard.shard_indices(world * B, rank, world)
-    frames = [synth.make_frame(W, H, seed=sd, K=1, fd=1, full_mask=(a.workload == "full")) for sd in seeds]
-    for b, f in enumerate(frames):
+    frames = [synth.make_frame(W, H, seed=sd, K=K, fd=a.fd, full_mask=(a.workload == "full")) for sd in seeds]
+    solves = [sg for f in frames for sg in synth.segment_masks(f)] if a.multseg else frames
+    S = len(solves)
+    for b, f in enumerate(solves):
         fs.set_frame(b, f["mask_red"], f["constraints"], rgb=f["rgb"])
     torch.cuda.synchronize()
 
     def step():
-        fs.solve(B, numIter, nIter, lIter)
-        fs.warp(B)
+        fs.solve(S, numIter, nIter, lIter)
+        fs.warp(S)
 
     def barrier():
         torch.cuda.synchronize()
@@ -119,7 +127,7 @@ def main():
     total_frames = world * B * a.steps
     fps = total_frames / dt
     pcg_per_frame = stats["pcg_iterations_per_frame"]
-    n_active = stats["active_vertices"] / B          # per frame
+    n_active = stats["active_vertices"] / B          # per frame (all its segments)
     n_grid = W * H
 
     out = {
@@ -127,12 +135,15 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: single %dx%d DAVIS-shaped frame, single-segment mask, fd=1; "
-                               "schedule %d/%d/%d" % (W, H, numIter, nIter, lIter)
+        "config": {"workload": ("configs[1]: single %dx%d DAVIS-shaped frame, single-segment mask, fd=%d; "
+                                "schedule %d/%d/%d" % (W, H, a.fd, numIter, nIter, lIter) if not a.multseg else
+                                "%dx%d --multseg, %d per-segment ARAP solves per frame batched on one GPU, fd=%d; "
+                                "schedule %d/%d/%d" % (W, H, K, a.fd, numIter, nIter, lIter))
                    if a.workload == "davis" else
                    "roofline config: %dx%d, mask == 0 (all vertices active), schedule %d/%d/%d"
                    % (W, H, numIter, nIter, lIter),
-                   "frames_per_gpu_per_step": B, "parallelism": "frames sharded, no collective",
+                   "frames_per_gpu_per_step": B, "segments_per_frame": K, "fd": a.fd,
+                   "parallelism": "frames sharded, no collective",
                    "active_vertices_per_frame": n_active, "grid_vertices_per_frame": n_grid},
         "pcg_iters_per_s": fps * pcg_per_frame,
         "hip_event_ms_per_step_rank0": ev_ms / a.steps,
@@ -143,7 +154,7 @@ def main():
         if not a.no_kernel_timing:
             tl = min(lIter, 400)
             st.set_kernel_timing(True)
-            fs.solve(B, 1, 2, tl)                      # 2 Gauss-Newton steps of tl PCG iterations
+            fs.solve(S, 1, 2, tl)                      # 2 Gauss-Newton steps of tl PCG iterations
             torch.cuda.synchronize()
             kt = {k: st.kernel_time(k) for k in ("PCGResident", "PCGStepA", "PCGStepB")}
             st.set_kernel_timing(False)
@@ -154,7 +165,7 @@ def main():
                 # algorithmic bytes: 160 B per active vertex per PCG iteration
                 bytes_total = 160.0 * n_act_total * tl * 2
                 ach = bytes_total / (tot_ms * 1e-3) / 1e9
-                frames_per_launch = B * 2.0 / n
+                frames_per_launch = S * 2.0 / n
                 out["roofline"] = {
                     "bound": "hbm", "kernel": "k_pcg_resident", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": tot_ms / n * 1e3, "launches": n,

@@ -4,6 +4,15 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# The CPU oracle is OpenMP code.  A 1-GPU box reports all host cores but grants 16 (cgroup): without a cap
+# libgomp starts one thread per reported core and the oracle runs ~10x slower.
+if "OMP_NUM_THREADS" not in os.environ:
+    try:
+        _n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        _n = os.cpu_count() or 1
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(_n, 16)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
