@@ -33,7 +33,7 @@ def build(force=False, verbose=False):
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC]
+    cmd = [hipcc] + FLAGS + os.environ.get("ARAPOPT_EXTRA_FLAGS", "").split() + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -45,6 +45,9 @@ constexpr int LTILE = 5 * LPLANE;        // float2 (px,py) plane | float2 (cos,s
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
                               + ((RES_MAX_HALO * 2 + 15) / 16) * 16   // halo list
                               + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (~74 KB: 2 per CU)
+#ifndef RES_PAIR_SLOTS
+#define RES_PAIR_SLOTS 1      // slots of phase A the scheduler may interleave (register pressure vs latency hiding)
+#endif
 constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
 
 struct ResDev {
@@ -319,7 +322,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         for (int j = 0; j < RES_SLOTS; ++j) {
             const int k = j;
             const unsigned f = fl[j];
-            if (f & F_ACT) {
+            {
+                // Branch free: every lane evaluates all four edges (LDS reads stay inside the halo'd tile) and
+                // keeps a contribution only where its flag bit is set, so the slots form one basic block and the
+                // scheduler can overlap one slot's LDS latency with another slot's arithmetic.  Selecting (not
+                // multiplying by 0) keeps NaNs of never-written halo cells out.
                 const float* T = lds + k * LTILE;
                 const float2 pv = TP2(T)[cell];
                 const float2 csv = TCS(T)[cell];                 // (ci, si)
@@ -329,62 +336,74 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const float2 a2 = make_float2(csv.x * pa_, csv.y * pa_);      // ( cp,  sp) = q pa for s=2
                 float2 axy = make_float2(0.f, 0.f);
                 float aa = 0.f;
-                // One block per stencil edge, written on (x,y) pairs so that they lower to packed-f32 ops.
                 // On the pixel grid d = U(c)-U(n) = -s, so q = R'(A(c))d and h = R'(A(n))d are signed copies
                 // of (si,ci) / (sn,cn); products with -1/0/1, adding a zero, x-(-y) = x+y and
                 // (-a)+(-b) = -(a+b) are exact, so each block equals the generic k_pcg_a expression
                 //   t = dP - q pa ; a_xy += wr2((e+t) - h qA) ; aa -= wr2(qx tx + qy ty)
                 // value for value (only the sign of an exact zero may differ).
-                if (f & F_E0) {   // s=(1,0): d=(-1,0)  q=( si,-ci)  h=( sn,-cn)
+                {   // s=(1,0): d=(-1,0)  q=( si,-ci)  h=( sn,-cn)
                     const int nc = cell + 1;
                     const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
                     const float qA = TPA(T)[nc];
                     const float2 e = pv - qO;
                     const float2 t = e - a0;
                     const float2 hq = make_float2(cn2.y * qA, -(cn2.x * qA));
-                    axy = axy + wr2 * ((e + t) - hq);
+                    const float2 nax = axy + wr2 * ((e + t) - hq);
                     const float2 m = scv * t;                    // (si tx, ci ty)
-                    aa = aa - wr2 * (m.x - m.y);
+                    const float naa = aa - wr2 * (m.x - m.y);
+                    const bool on = (f & F_E0) != 0;
+                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
                 }
-                if (f & F_E1) {   // s=(-1,0): d=(1,0)  q=(-si, ci)  h=(-sn, cn)
+                {   // s=(-1,0): d=(1,0)  q=(-si, ci)  h=(-sn, cn)
                     const int nc = cell - 1;
                     const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
                     const float qA = TPA(T)[nc];
                     const float2 e = pv - qO;
                     const float2 t = e + a0;
                     const float2 hq = make_float2(cn2.y * qA, -(cn2.x * qA));
-                    axy = axy + wr2 * ((e + t) + hq);
+                    const float2 nax = axy + wr2 * ((e + t) + hq);
                     const float2 m = scv * t;
-                    aa = aa - wr2 * (m.y - m.x);
+                    const float naa = aa - wr2 * (m.y - m.x);
+                    const bool on = (f & F_E1) != 0;
+                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
                 }
-                if (f & F_E2) {   // s=(0,1): d=(0,-1)  q=( ci, si)  h=( cn, sn)
+                {   // s=(0,1): d=(0,-1)  q=( ci, si)  h=( cn, sn)
                     const int nc = cell + LROW;
                     const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
                     const float qA = TPA(T)[nc];
                     const float2 e = pv - qO;
                     const float2 t = e - a2;
                     const float2 hq = cn2 * qA;
-                    axy = axy + wr2 * ((e + t) - hq);
+                    const float2 nax = axy + wr2 * ((e + t) - hq);
                     const float2 m = csv * t;                    // (ci tx, si ty)
-                    aa = aa - wr2 * (m.x + m.y);
+                    const float naa = aa - wr2 * (m.x + m.y);
+                    const bool on = (f & F_E2) != 0;
+                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
                 }
-                if (f & F_E3) {   // s=(0,-1): d=(0,1)  q=(-ci,-si)  h=(-cn,-sn)
+                {   // s=(0,-1): d=(0,1)  q=(-ci,-si)  h=(-cn,-sn)
                     const int nc = cell - LROW;
                     const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
                     const float qA = TPA(T)[nc];
                     const float2 e = pv - qO;
                     const float2 t = e + a2;
                     const float2 hq = cn2 * qA;
-                    axy = axy + wr2 * ((e + t) + hq);
+                    const float2 nax = axy + wr2 * ((e + t) + hq);
                     const float2 m = csv * t;
-                    aa = aa + wr2 * (m.x + m.y);
+                    const float naa = aa + wr2 * (m.x + m.y);
+                    const bool on = (f & F_E3) != 0;
+                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
                 }
-                if (f & F_FIT) axy = axy + wf2 * pv;
+                {
+                    const float2 nax = axy + wf2 * pv;
+                    const bool on = (f & F_FIT) != 0;
+                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y;
+                }
                 const float ax = axy.x, ay = axy.y;
                 apx[j] = ax; apy[j] = ay; apa[j] = aa;
-                acc += (double)dot3(pv.x, pv.y, pa_, ax, ay, aa);
+                const float dt = dot3(pv.x, pv.y, pa_, ax, ay, aa);
+                acc += (f & F_ACT) ? (double)dt : 0.0;
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (RES_PAIR_SLOTS == 1 || (j % RES_PAIR_SLOTS) == RES_PAIR_SLOTS - 1) __builtin_amdgcn_sched_barrier(0);
         }
         float sigma;
         RES_STAMP(tA);
