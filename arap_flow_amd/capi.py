@@ -48,6 +48,7 @@ SYMBOLS = [
     ("ArapFlow_SolverStats", _I, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("ArapFlow_SetResident", None, [_VP, _I]),
     ("ArapFlow_SolverResidentLaunches", C.c_uint64, [_VP]),
+    ("ArapFlow_PlanResidentLaunches", C.c_uint64, [_VP]),
     ("ArapFlow_SolverStamps", _I, [_VP, _VP]),
     ("ArapFlow_WarpScratchBytes", C.c_uint64, [_U, _U]),
     ("ArapFlow_Warp", _I, [_VP, _U, _U, _VP, _VP, _VP, _VP, _VP, _VP]),

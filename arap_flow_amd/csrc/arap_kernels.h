@@ -62,6 +62,28 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Opt_ProblemInit analysis for the resident path of the drop-in API: which 64x4 tiles hold an active vertex,
+// and is UrShape the pixel grid on every active vertex (then d = U(c)-U(n) = -s on every valid edge, which is
+// what arap_resident.h specialises on; the application always passes that grid, CombinedSolver.h:207-221).
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_analyse(PlanDev pd, int* not_grid)
+{
+    const VIdx v = vidx(pd);
+    const Slot sl = pd.slots[v.b];
+    int act = 0, bad = 0;
+    if (v.in && sl.M[v.i] == 0.0f) {
+        act = 1;
+        const float2 u = sl.U[v.i];
+        bad = !(u.x == (float)v.x && u.y == (float)v.y);
+    }
+    const int any = __syncthreads_or(act);
+    const int anybad = __syncthreads_or(bad);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
+        if (anybad) atomicOr(not_grid, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PCGInit1: delta = 0; (g, D) = evalJTF; r = -g; pre = guardedInvert(D); p = pre*r; rho0 += r.p
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
 {

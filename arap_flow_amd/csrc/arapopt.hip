@@ -122,6 +122,10 @@ struct Opt_Plan {
     void* res_block = nullptr;
     std::vector<int> h_ntiles;
     unsigned res_launches = 0;
+    // drop-in (Opt_*) plans: result of the Init-time analysis (k_analyse) of the caller's Mask / UrShape
+    bool opt_res_ok = false;
+    Slot opt_res_slot{};
+    int* d_notgrid = nullptr;
 
     dim3 grid() const { return dim3(pd.tilesX, pd.tilesY, nb); }
     dim3 blk() const { return dim3(TILE_X, TILE_Y, 1); }
@@ -204,12 +208,49 @@ static void plan_enable_resident(Opt_Plan* p)
         HC(hipMemset(p->rd.stamps, 0, RES_WGS * 8 * sizeof(unsigned long long)));
     }
     p->res_capable = true;
-    p->res_frames = true;
+}
+
+// Opt_ProblemInit: look at the caller's Mask and UrShape once (the reference's init also blocks on a device
+// read-back, solverGPUGaussNewton.t:1006,790-797) to decide whether the Steps can take the resident kernel.
+static void plan_analyse_for_resident(Opt_Plan* p)
+{
+    p->opt_res_ok = false;
+    if (!p->res_capable || p->res_frames || !p->st->use_resident) return;
+    Opt_State* st = p->st;
+    if (!p->d_notgrid) HC(hipMalloc(&p->d_notgrid, sizeof(int)));
+    HC(hipMemsetAsync(p->d_notgrid, 0, sizeof(int), st->stream));
+    hipLaunchKernelGGL(k_analyse, p->grid(), p->blk(), 0, st->stream, p->pd, p->d_notgrid);
+    const int nt_all = p->pd.tilesX * p->pd.tilesY;
+    std::vector<uint8_t> act(nt_all);
+    int notgrid = 1;
+    HC(hipMemcpyAsync(act.data(), p->pd.tileact, nt_all, hipMemcpyDeviceToHost, st->stream));
+    HC(hipMemcpyAsync(&notgrid, p->d_notgrid, sizeof(int), hipMemcpyDeviceToHost, st->stream));
+    HC(hipStreamSynchronize(st->stream));
+    if (notgrid) return;
+    std::vector<int> tiles;
+    for (int t = 0; t < nt_all; ++t)
+        if (act[t]) tiles.push_back(t);
+    const int nt = (int)tiles.size();
+    p->h_ntiles[0] = nt;
+    if (nt > RES_MAX_TILES) return;
+    if (nt > 0)
+        HC(hipMemcpyAsync((void*)p->rd.tilelist, tiles.data(), sizeof(int) * nt, hipMemcpyHostToDevice, st->stream));
+    HC(hipMemcpyAsync((void*)p->rd.ntiles, &nt, sizeof(int), hipMemcpyHostToDevice, st->stream));
+    HC(hipStreamSynchronize(st->stream));       // `tiles` is a local
+    p->opt_res_ok = true;
+    p->opt_res_slot = p->hslots[0];
 }
 
 static bool plan_resident_eligible(const Opt_Plan* p)
 {
-    if (!p->res_capable || !p->res_frames || !p->st->use_resident) return false;
+    if (!p->res_capable || !p->st->use_resident) return false;
+    if (!p->res_frames) {
+        // drop-in plan: only with the images that were analysed at Init (the caller may swap buffers between
+        // Steps, solverGPUGaussNewton.t:1026; then the general two-kernel path runs)
+        const Slot& a = p->opt_res_slot;
+        const Slot& c = p->hslots[0];
+        if (!p->opt_res_ok || a.M != c.M || a.U != c.U) return false;
+    }
     for (int b = 0; b < p->nb; ++b)
         if (p->h_ntiles[b] > RES_MAX_TILES) return false;
     return true;
@@ -255,6 +296,7 @@ static void plan_free(Opt_Plan* p)
     if (p->pd.red) (void)hipFree(p->pd.red);
     if (p->pd.costred) (void)hipFree(p->pd.costred);
     if (p->res_block) (void)hipFree(p->res_block);
+    if (p->d_notgrid) (void)hipFree(p->d_notgrid);
     if (p->block) (void)hipFree(p->block);
     delete p;
 }
@@ -419,6 +461,7 @@ static void plan_init(Opt_Plan* p)
     p->sp.nIter = 0;
     plan_reserve(p, p->sp.lIterations, p->sp.nIterations + 1);
     plan_upload_slots(p);
+    plan_analyse_for_resident(p);
     HC(hipMemsetAsync(p->pd.costred, 0, (size_t)p->nb * p->pd.ncost * NSHARD * sizeof(double), p->st->stream));
     plan_cost(p, 0);
 }
@@ -581,7 +624,9 @@ Opt_Plan* Opt_ProblemPlan(Opt_State* state, Opt_Problem* problem, unsigned int* 
         fprintf(stderr, "arapopt: bad dimensions %u x %u\n", W, H);
         return nullptr;
     }
-    return plan_create(state, (int)W, (int)H, 1);
+    Opt_Plan* p = plan_create(state, (int)W, (int)H, 1);
+    plan_enable_resident(p);
+    return p;
 }
 
 void Opt_PlanFree(Opt_State*, Opt_Plan* plan) { plan_free(plan); }
@@ -799,6 +844,7 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
     s->st = st; s->W = (int)W; s->H = (int)H; s->N = (int)(W * H); s->batch = (int)batch;
     s->plan = plan_create(st, (int)W, (int)H, (int)batch);
     plan_enable_resident(s->plan);
+    s->plan->res_frames = s->plan->res_capable;
     const size_t N = s->N;
     const size_t sz2 = align_up(N * sizeof(float2), 256), sz1 = align_up(N * sizeof(float), 256);
     const size_t szb = align_up(N, 256), sz3 = align_up(3 * N, 256), szk = align_up(N * 8, 256);
@@ -971,6 +1017,7 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg, uint64_t* active, ui
 }
 
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s) { return s ? s->plan->res_launches : 0; }
+uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan) { return plan ? plan->res_launches : 0; }
 
 // diagnostic (ARAPOPT_STAMPS=1): copy the [256][8] phase-time table of the LAST resident launch
 int ArapFlow_SolverStamps(ArapFlow_Solver* s, uint64_t* out)

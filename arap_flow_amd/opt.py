@@ -139,6 +139,9 @@ class OptSolver:
     def current_cost(self):
         return self.lib.Opt_ProblemCurrentCost(self.state.handle, self.plan)
 
+    def resident_launches(self):
+        return int(self.lib.ArapFlow_PlanResidentLaunches(self.plan))
+
     def close(self):
         if self.plan:
             self.lib.Opt_PlanFree(self.state.handle, self.plan)

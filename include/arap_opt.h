@@ -184,6 +184,11 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg_iterations_per_frame,
  * ArapFlow_SolverResidentLaunches counts resident launches since the solver was created. */
 void ArapFlow_SetResident(Opt_State* state, int on);
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s);
+/* The drop-in path (Opt_ProblemInit/Step/Solve) takes the resident kernel too when, at Init, the caller's
+ * UrShape is the pixel grid on every active vertex (what the application passes, CombinedSolver.h:207-221) and
+ * the active tiles fit; the Mask/UrShape buffers analysed at Init must then stay the ones passed to the Steps
+ * (other buffers -> general two-kernel path).  Counts resident launches enqueued/captured for this plan. */
+uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan);
 /* Diagnostic only (env ARAPOPT_STAMPS=1 selects an instrumented build of the resident kernel): copies
  * out[512][8] = per workgroup {phase A, wait 1, phase B, wait 2, update} summed 100 MHz ticks of the
  * last resident launch, tiles per workgroup, halo cells.  Returns -1 when stamps are off. */

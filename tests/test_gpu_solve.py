@@ -237,3 +237,26 @@ def test_multseg_segments_batched_equal_separate_solves(gpu_state):
         one.close()
         assert np.array_equal(r["offset"], together[b]["offset"]) and np.array_equal(r["angle"], together[b]["angle"])
         assert np.all(together[b]["flow"][s["mask_red"] != 0] == 0)
+
+
+def test_drop_in_api_takes_resident_kernel_only_for_grid_urshape(gpu_state, oracle):
+    """Opt_ProblemSolve analyses Mask/UrShape at Init: pixel-grid UrShape -> resident kernel, generic UrShape ->
+    two-kernel path; both equal the float32 oracle bit for bit."""
+    W, H = 150, 90
+    for generic in (False, True):
+        pb = helpers.random_problem(W, H, seed=77, generic_urshape=generic, ncons=60)
+        dev = {k: torch.from_numpy(pb[k].copy()).cuda() for k in "OAUCM"}
+        s = opt.OptSolver(gpu_state, (W, H))
+        pp = opt.NamedParameters()
+        for n, k in [("Offset", "O"), ("Angle", "A"), ("UrShape", "U"), ("Constraints", "C"), ("Mask", "M")]:
+            pp.set(n, dev[k])
+        pp.set("w_fitSqrt", 10.0); pp.set("w_regSqrt", 0.1)
+        sp = opt.NamedParameters()
+        sp.set("nIterations", 2); sp.set("lIterations", 40)
+        cost = s.solve(sp, pp)
+        assert (s.resident_launches() > 0) == (not generic)
+        s.close()
+        Or, Ar, costs = oracle.solve(pb["O"], pb["A"], pb["U"], pb["C"], pb["M"], 10.0, 0.1, 2, 40, dtype=np.float32,
+                                     mode=1, trig=1)
+        assert np.array_equal(dev["O"].cpu().numpy(), Or) and np.array_equal(dev["A"].cpu().numpy(), Ar)
+        assert cost == costs[-1]
