@@ -67,10 +67,26 @@ def cpu_baseline(frame, schedule):
               dtype=np.float32, mode=1, trig=1)
     dt = time.time() - t0
     fps = 1.0 / (dt * numIter)
-    return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 of %d ramp steps (%d GN x %d PCG iterations) of one frame of the same workload, "
-                      "%.1f s, scaled x%d" % (numIter, nIter, lIter, dt, numIter),
-            "pcg_iters_per_s": nIter * lIter / dt}
+    out = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "1 of %d ramp steps (%d GN x %d PCG iterations) of one frame of the same workload, "
+                     "%.1f s, scaled x%d" % (numIter, nIter, lIter, dt, numIter),
+           "pcg_iters_per_s": nIter * lIter / dt}
+    # the same code on ONE thread (SURVEY 8d asks for both), on a smaller sample: 1 GN step
+    import subprocess
+    code = ("import os,sys,time,json,numpy as np;sys.path.insert(0,%r);from oracle import oracle as orc;"
+            "from arap_flow_amd import synth;f=synth.make_frame(%d,%d,seed=%d,full_mask=%r);t=time.time();"
+            "orc.frame(f['mask_red'],f['constraints'],numIter=1,nIterations=1,lIterations=%d,dtype=np.float32,mode=1,trig=1);"
+            "print(json.dumps(time.time()-t))" % (ROOT, frame["mask_red"].shape[1], frame["mask_red"].shape[0],
+                                                  frame.get("seed", 0), bool((frame["mask_red"] == 0).all()), lIter))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"),
+                           capture_output=True, text=True, timeout=300)
+        t1 = float(r.stdout.strip().splitlines()[-1])
+        out["single_thread"] = {"value": 1.0 / (t1 * nIter * numIter), "unit": "frames/s", "cores": 1,
+                                "sample": "1 GN step (%d PCG iterations), %.1f s, scaled x%d" % (lIter, t1, nIter * numIter)}
+    except Exception as e:                                    # never fail the bench over the extra figure
+        out["single_thread"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():
@@ -95,7 +111,8 @@ def main():
     fs = opt.FrameSolver(st, W, H, batch=S)
     # the job's frame list (world x B frames per step) is dealt round-robin to the ranks: no collective
     seeds = shard.shard_indices(world * B, rank, world)
-    frames = [synth.make_frame(W, H, seed=sd, K=K, fd=a.fd, full_mask=(a.workload == "full")) for sd in seeds]
+    frames = [dict(synth.make_frame(W, H, seed=sd, K=K, fd=a.fd, full_mask=(a.workload == "full")), seed=sd)
+              for sd in seeds]
     solves = [sg for f in frames for sg in synth.segment_masks(f)] if a.multseg else frames
     S = len(solves)
     for b, f in enumerate(solves):
