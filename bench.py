@@ -49,41 +49,43 @@ def parse():
     return ap.parse_args()
 
 
+def _time_oracle(frame, threads, numIter, nIter, lIter):
+    """wall time of the CPU oracle in a FRESH process (OMP_NUM_THREADS must be set before the OpenMP runtime starts;
+    this process already runs torch's)"""
+    import subprocess
+    H, W = frame["mask_red"].shape
+    code = ("import sys,time,json,numpy as np;sys.path.insert(0,%r);from oracle import oracle as orc;"
+            "from arap_flow_amd import synth;f=synth.make_frame(%d,%d,seed=%d,full_mask=%r);t=time.time();"
+            "orc.frame(f['mask_red'],f['constraints'],numIter=%d,nIterations=%d,lIterations=%d,dtype=np.float32,mode=1,trig=1);"
+            "print(json.dumps(time.time()-t))" % (ROOT, W, H, frame.get("seed", 0), bool((frame["mask_red"] == 0).all()),
+                                                  numIter, nIter, lIter))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="active"),
+                       capture_output=True, text=True, timeout=900)
+    return float(r.stdout.strip().splitlines()[-1])
+
+
 def cpu_baseline(frame, schedule):
-    """The CPU oracle (same algorithm, float32, OpenMP over rows) on a bounded sample of the same
-    workload: one ramp step of the same frame (nIterations x lIterations PCG iterations), scaled by
-    the number of ramp steps.  Only this leg of the bench touches oracle/."""
-    from oracle import oracle as orc
-    # threads = this process's CPU share (a 1-GPU box grants 16 of the host's cores), not the host total
+    """The CPU oracle (same algorithm, float32, OpenMP over rows; kind "port") on a bounded sample of the same
+    workload, on this box's CPU share (a 1-GPU box grants 16 of the host's cores).  Only this leg of the bench
+    touches oracle/."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = min(cores, int(os.environ.get("ARAP_CPU_BASELINE_THREADS", "16")))
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     numIter, nIter, lIter = schedule
-    t0 = time.time()
-    orc.frame(frame["mask_red"], frame["constraints"], numIter=1, nIterations=nIter, lIterations=lIter,
-              dtype=np.float32, mode=1, trig=1)
-    dt = time.time() - t0
-    fps = 1.0 / (dt * numIter)
+    ns = min(numIter, 19)
+    dt = _time_oracle(frame, cores, ns, nIter, lIter)
+    fps = 1.0 / (dt * numIter / ns)
     out = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "1 of %d ramp steps (%d GN x %d PCG iterations) of one frame of the same workload, "
-                     "%.1f s, scaled x%d" % (numIter, nIter, lIter, dt, numIter),
-           "pcg_iters_per_s": nIter * lIter / dt}
-    # the same code on ONE thread (SURVEY 8d asks for both), on a smaller sample: 1 GN step
-    import subprocess
-    code = ("import os,sys,time,json,numpy as np;sys.path.insert(0,%r);from oracle import oracle as orc;"
-            "from arap_flow_amd import synth;f=synth.make_frame(%d,%d,seed=%d,full_mask=%r);t=time.time();"
-            "orc.frame(f['mask_red'],f['constraints'],numIter=1,nIterations=1,lIterations=%d,dtype=np.float32,mode=1,trig=1);"
-            "print(json.dumps(time.time()-t))" % (ROOT, frame["mask_red"].shape[1], frame["mask_red"].shape[0],
-                                                  frame.get("seed", 0), bool((frame["mask_red"] == 0).all()), lIter))
-    try:
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"),
-                           capture_output=True, text=True, timeout=300)
-        t1 = float(r.stdout.strip().splitlines()[-1])
-        out["single_thread"] = {"value": 1.0 / (t1 * nIter * numIter), "unit": "frames/s", "cores": 1,
-                                "sample": "1 GN step (%d PCG iterations), %.1f s, scaled x%d" % (lIter, t1, nIter * numIter)}
+           "sample": "%d of %d ramp steps (x %d GN x %d PCG iterations) of one frame of the same workload, %.1f s"
+                     % (ns, numIter, nIter, lIter, dt),
+           "pcg_iters_per_s": ns * nIter * lIter / dt}
+    try:                                                      # the same code on ONE thread (SURVEY 8d asks for both)
+        n1 = min(nIter, 8)
+        t1 = _time_oracle(frame, 1, 1, n1, lIter)
+        out["single_thread"] = {"value": 1.0 / (t1 * numIter * nIter / n1), "unit": "frames/s", "cores": 1,
+                                "sample": "1 ramp step x %d GN x %d PCG iterations, %.1f s, scaled" % (n1, lIter, t1)}
     except Exception as e:                                    # never fail the bench over the extra figure
         out["single_thread"] = {"error": str(e)[:200]}
     return out
