@@ -40,5 +40,35 @@ def build(force=False, verbose=False):
     return OUT
 
 
+HOST_DIR = os.path.join(HERE, "host")
+BIN_DIR = os.path.join(HERE, "bin")
+HOST_PROGRAMS = {"arap_deform": ["arap_deform.cpp", "png_io.cpp"], "warp_image": ["warp_image.cpp", "png_io.cpp"],
+                 "png_tool": ["png_tool.cpp", "png_io.cpp"]}
+
+
+def build_host(force=False, verbose=False):
+    """C++ host programs (the reference's drivers are C++: ARAP/deformation/src/main.cpp, ARAP/warping/src/main.cpp)
+    linked against libarapopt.so: arap_flow_amd/bin/arap_deform, arap_flow_amd/bin/warp_image."""
+    build(force=False)
+    os.makedirs(BIN_DIR, exist_ok=True)
+    outs = []
+    for name, srcs in HOST_PROGRAMS.items():
+        out = os.path.join(BIN_DIR, name)
+        deps = [os.path.join(HOST_DIR, f) for f in srcs + ["png_io.h", "flo_io.h"]] + [OUT]
+        if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+            outs.append(out)
+            continue
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + \
+              [os.path.join(HOST_DIR, f) for f in srcs] + \
+              ["-o", out, "-L" + OUT_DIR, "-larapopt", "-Wl,-rpath,$ORIGIN/../lib", "-L/opt/rocm/lib", "-lamdhip64",
+               "-Wl,-rpath,/opt/rocm/lib", "-lz"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_host(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,185 @@
+// arap_deform -- C++ host program over libarapopt.so with the argv contract, schedule and outputs of the
+// reference's executable (ARAP/deformation/src/main.cpp:162-241 + CombinedSolver.h + CombinedSolverBase.h):
+//   ./arap_deform RGB Mask Constraint Flow warped_RGB warped_Mask        (one frame)
+//   ./arap_deform listfile                                               (six paths per line)
+// The reference keeps one CombinedSolver (one Opt plan) and feeds it frame after frame (main.cpp:223-238);
+// here consecutive frames of equal size are handed to the device-resident batched solver eight at a time
+// (ArapFlow_Solver = CombinedSolver on the GPU: reset, 19-step constraint ramp, 8 GN x 400 PCG, flow, rasteriser).
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "../../include/arap_opt.h"
+}
+#include "flo_io.h"
+#include "png_io.h"
+
+struct inputPaths {                      // main.cpp:4-11
+    std::string inp_imgPath, inp_mskPath, inp_cstrPath, out_floPath, out_imgPath, out_mskPath;
+};
+
+static void usage()
+{
+#define p(msg) printf(msg "\n");
+    p("Usage:\n");
+    p("./arap_deform RGB Mask Constraint Flow warped_RGB warped_Mask\n");
+    p("Mask and warp image using the provided optical flow field.\n")
+    p("RGB \t\t [input]  path to an input RGB image (.png only)")
+    p("Mask\t\t [input]  path to an input mask image (.png only) where 0 for object, 1 for background")
+    p("Constraint \t [input]  path to list of constraints, text file")
+    p("Flow \t\t [output] path to optical flow image with (.flo only)")
+    p("warped_RGB \t [output] path to output warped image (.png), all intermediate directories must exist")
+    p("warped_Mask \t [output] path to output warped mask (.png), all intermediate directories must exist")
+#undef p
+}
+
+// main.cpp:26-50
+static bool loadConstraints(std::vector<int32_t>& constraints, const std::string& path)
+{
+    std::ifstream in(path, std::fstream::in);
+    if (!in.good()) {
+        std::cout << "Could not open marker file " << path << std::endl;
+        return false;
+    }
+    unsigned int nMarkers = 0;
+    in >> nMarkers;
+    constraints.clear();
+    for (unsigned int m = 0; m < nMarkers; m++)
+        for (int i = 0; i < 4; ++i) {
+            int temp = 0;
+            in >> temp;
+            constraints.push_back(temp);
+        }
+    return true;
+}
+
+struct Frame {
+    inputPaths paths;
+    arapio::Image rgb;
+    std::vector<uint8_t> mask_red;
+    std::vector<int32_t> constraints;      // x1 y1 x2 y2 rows, file order then border pins
+};
+
+// loadData, main.cpp:116-138: constraints file, PNGs, then a pin-to-self constraint for every border pixel
+static bool loadData(const inputPaths& paths, Frame& f)
+{
+    f.paths = paths;
+    if (!loadConstraints(f.constraints, paths.inp_cstrPath)) return false;
+    std::string err;
+    if (!arapio::read_png_rgb(paths.inp_imgPath, f.rgb, err)) { printf("%s\n", err.c_str()); return false; }
+    arapio::Image msk;
+    if (!arapio::read_png_rgb(paths.inp_mskPath, msk, err)) { printf("%s\n", err.c_str()); return false; }
+    if (msk.w != f.rgb.w || msk.h != f.rgb.h) {
+        printf("Mask %s and image %s differ in size\n", paths.inp_mskPath.c_str(), paths.inp_imgPath.c_str());
+        return false;
+    }
+    const int width = f.rgb.w, height = f.rgb.h;
+    f.mask_red.resize((size_t)width * height);
+    for (size_t i = 0; i < f.mask_red.size(); ++i) f.mask_red[i] = msk.rgb[3 * i];      // red channel
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++)
+            if (y == 0 || x == 0 || y == (height - 1) || x == (width - 1)) {
+                f.constraints.push_back(x); f.constraints.push_back(y);
+                f.constraints.push_back(x); f.constraints.push_back(y);
+            }
+    return true;
+}
+
+int main(int argc, const char* argv[])
+{
+    std::vector<inputPaths> lines;
+    inputPaths one;
+    if (argc == 7) {
+        one.inp_imgPath = argv[1]; one.inp_mskPath = argv[2]; one.inp_cstrPath = argv[3];
+        one.out_floPath = argv[4]; one.out_imgPath = argv[5]; one.out_mskPath = argv[6];
+        lines.push_back(one);
+    } else if (argc == 2) {
+        std::ifstream infile(argv[1]);
+        std::string line;
+        while (getline(infile, line)) {
+            std::stringstream s(line);
+            inputPaths q;
+            s >> q.inp_imgPath >> q.inp_mskPath >> q.inp_cstrPath >> q.out_floPath >> q.out_imgPath >> q.out_mskPath;
+            if (!q.out_mskPath.empty()) lines.push_back(q);
+        }
+    } else {
+        printf("Invalid Input!\n");
+        usage();
+        return 1;
+    }
+    if (lines.empty()) {
+        printf("No file to be processed");
+        return 1;
+    }
+    Opt_InitializationParameters ip = {0, 0, 0, 0};
+    Opt_State* state = Opt_NewState(ip);
+    if (!state) return 1;
+    const char* planPath = getenv("ARAP_PLAN");                          // main.cpp:206-213
+    if (planPath) {
+        printf("Optimization plan at %s\n", planPath);
+        std::ifstream f(planPath);
+        if (!f.good()) {
+            printf(" Not found! Please run export ARAP_PLAN=/path/to/plan.t or copy the file to the running folder "
+                   "with name arap_plan.t");
+            return 1;
+        }
+        Opt_Problem* pr = Opt_ProblemDefine(state, planPath, "gaussNewtonGPU");
+        if (!pr) return 1;
+        Opt_ProblemDelete(state, pr);
+    }
+    const unsigned numIter = 19, nonLinearIter = 8, linearIter = 400;    // main.cpp:215-221
+    const unsigned maxBatch = 8;
+
+    ArapFlow_Solver* solver = nullptr;
+    int sw = 0, sh = 0;
+    size_t i = 0;
+    while (i < lines.size()) {
+        std::vector<Frame> batch(1);
+        if (!loadData(lines[i], batch[0])) return 1;
+        const int w = batch[0].rgb.w, h = batch[0].rgb.h;
+        size_t j = i + 1;
+        while (j < lines.size() && batch.size() < maxBatch) {
+            Frame f;
+            if (!loadData(lines[j], f)) return 1;
+            if (f.rgb.w != w || f.rgb.h != h) break;                     // next batch starts here (re-read then)
+            batch.push_back(std::move(f));
+            ++j;
+        }
+        if (w != sw || h != sh) {
+            if (solver) {
+                printf("Warning: Input image has different size to one in the prebuilt plan.\n"
+                       "To avoid re-building the plan and to save time, put images of the same size in the same list.\n"
+                       "Starting to re-build plan...\n");                // CombinedSolver.h:151-153
+                ArapFlow_SolverFree(solver);
+            }
+            solver = ArapFlow_SolverCreate(state, (unsigned)w, (unsigned)h, maxBatch);
+            if (!solver) return 1;
+            sw = w; sh = h;
+        }
+        for (size_t b = 0; b < batch.size(); ++b)                         // addImage
+            if (ArapFlow_SolverSetFrame(solver, (unsigned)b, batch[b].rgb.rgb.data(), batch[b].mask_red.data(),
+                                        batch[b].constraints.data(), (unsigned)(batch[b].constraints.size() / 4), 0) != 0)
+                return 1;
+        ArapFlow_SolverSolve(solver, (unsigned)batch.size(), numIter, nonLinearIter, linearIter);   // solveAll
+        ArapFlow_SolverWarp(solver, (unsigned)batch.size());
+        std::vector<float> flow((size_t)w * h * 2);
+        std::vector<uint8_t> wrgb((size_t)w * h * 3), wmsk((size_t)w * h);
+        for (size_t b = 0; b < batch.size(); ++b) {
+            ArapFlow_SolverGetResults(solver, (unsigned)b, flow.data(), wrgb.data(), wmsk.data(), nullptr, nullptr, nullptr);
+            std::string err;
+            if (!arapio::write_png_rgb(batch[b].paths.out_imgPath, w, h, wrgb.data(), err)) printf("%s\n", err.c_str());
+            if (!arapio::write_png_mask1(batch[b].paths.out_mskPath, w, h, wmsk.data(), err)) printf("%s\n", err.c_str());
+            arapio::write_flo(batch[b].paths.out_floPath, flow.data(), w, h);
+            printf("Saved\n");
+        }
+        i = j;
+    }
+    if (solver) ArapFlow_SolverFree(solver);
+    ArapFlow_FreeState(state);
+    return 0;
+}

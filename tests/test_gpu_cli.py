@@ -89,3 +89,61 @@ def test_para_gen_end_to_end(tmp_path, multseg):
     lab = np.array(Image.open(inp / "orgMasks" / "a" / "00000.png"))
     assert abs(int((wm != 0).sum()) - int((lab != 0).sum())) < 0.2 * (lab != 0).sum()
     assert not [f for f in os.listdir(outp / "Flow" / "a") if "_seg" in f]          # flattened and removed
+
+
+def _bins():
+    from arap_flow_amd import build
+    return {osp.basename(o): o for o in build.build_host()}
+
+
+def test_cpp_warp_image_reproduces_reference_fixture(tmp_path, golden_dir):
+    b = _bins()
+    d = osp.join(golden_dir, "cat512")
+    r = subprocess.run([b["warp_image"], osp.join(d, "cat512_iRGB.png"), osp.join(d, "cat512_iMsk.png"),
+                        osp.join(d, "cat512_iFlo.flo"), str(tmp_path / "o.png"), str(tmp_path / "om.png")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Saved" in r.stdout, r.stdout + r.stderr
+    cat = helpers.load_cat512(golden_dir)
+    assert np.array_equal(np.array(Image.open(tmp_path / "om.png").convert("L")), cat["golden_wmsk"])
+    diff = np.abs(np.array(Image.open(tmp_path / "o.png").convert("RGB")).astype(int) - cat["golden_wrgb"].astype(int))
+    assert diff.max() <= 1 and (diff.max(-1) > 0).mean() < 0.005
+
+
+def test_cpp_arap_deform_equals_python_twin_and_serves_para_gen(tmp_path, gpu_state):
+    """the C++ driver (arap_flow_amd/host/arap_deform.cpp) writes the same .flo / PNG content as the library path,
+    and para_gen.py accepts it as --arap_bin exactly like the reference's executable"""
+    b = _bins()
+    frames = [synth.make_frame(96, 64, seed=5), synth.make_frame(96, 64, seed=6), synth.make_frame(70, 50, seed=7)]
+    lines = []
+    for k, f in enumerate(frames):
+        Image.fromarray(f["rgb"]).save(tmp_path / ("r%d.png" % k))
+        Image.fromarray(f["mask_red"]).save(tmp_path / ("m%d.png" % k))                 # greyscale mask PNG
+        pipeline.write_constraints(str(tmp_path / ("c%d.txt" % k)), [tuple(c) for c in f["constraints"]])
+        lines.append(" ".join(str(tmp_path / (n % k)) for n in ("r%d.png", "m%d.png", "c%d.txt", "f%d.flo", "w%d.png", "wm%d.png")))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    r = subprocess.run([b["arap_deform"], str(tmp_path / "list.txt")], capture_output=True, text=True, timeout=600,
+                       cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.count("Saved") == 3, r.stdout + r.stderr
+    assert "Starting to re-build plan" in r.stdout                                        # third frame has another size
+    for k, f in enumerate(frames):
+        H, W = f["mask_red"].shape
+        fs = opt.FrameSolver(gpu_state, W, H, batch=1)
+        fs.set_frame(0, f["mask_red"], f["constraints"], rgb=f["rgb"])
+        fs.solve(1, 19, 8, 400); fs.warp(1)
+        ref = fs.results(0); fs.close()
+        assert np.array_equal(flo.flow_read(str(tmp_path / ("f%d.flo" % k))), ref["flow"])
+        assert np.array_equal(np.array(Image.open(tmp_path / ("w%d.png" % k))), ref["warped_rgb"])
+        wm = Image.open(tmp_path / ("wm%d.png" % k))
+        assert wm.mode == "1" and np.array_equal(np.array(wm), ref["warped_mask"] > 0)
+    # para_gen with the C++ executable as --arap_bin
+    inp, outp, mdir = tmp_path / "in", tmp_path / "out", tmp_path / "matches"
+    os.makedirs(inp / "orgRGB" / "s"); os.makedirs(inp / "orgMasks" / "s"); os.makedirs(mdir / "s")
+    fr = synth.make_frame(96, 64, seed=11, K=2)
+    for n in range(2):
+        Image.fromarray(fr["rgb"]).save(inp / "orgRGB" / "s" / ("%05d.png" % n))
+        Image.fromarray(fr["labels"].astype(np.uint8)).save(inp / "orgMasks" / "s" / ("%05d.png" % n))
+        (mdir / "s" / ("%05d.txt" % n)).write_text("\n".join("%d %d %d %d 1.0 0" % tuple(c) for c in fr["constraints"]))
+    _run([osp.join(ROOT, "para_gen.py"), "--input", str(inp), "--output", str(outp), "--gpu", "0", "--matches", str(mdir),
+          "--multseg", "--arap_bin", b["arap_deform"]], str(tmp_path))
+    lst = open(outp / "all_files.list").read().splitlines()
+    assert len(lst) == 1 and np.abs(flo.flow_read(lst[0].split(" ")[2])).max() > 0.5
