@@ -52,6 +52,11 @@ struct PlanDev {
     double* red;             // [batch][nslots][NSHARD]  PCG scalars of the current GN step
     double* costred;         // [batch][ncost][NSHARD]   cost after Init (index 0) and after each step
     int ncost;
+    // "LMGPU" solver kind only (arap_lm.h); lm == 0 for Gauss-Newton plans
+    int lm;
+    float2 *bO, *CtCO, *SSqO, *AdO;
+    float *bA, *CtCA, *SSqA, *AdA;
+    double* lmred;           // [lIterations + 2][NSHARD]: q after iteration l at l+1 (Q0 at 0), model cost last
 };
 
 // ---- cos/sin: same operation list as oracle/arap_oracle.c:arap_sincos_spec ----------------------
@@ -136,6 +141,26 @@ __device__ __forceinline__ void block_reduce_atomic(double v, double* target_sha
         if (t != 0.0)   // adding an exact zero changes nothing: skip the memory-side atomic
             __hip_atomic_fetch_add(target_shards + (wg_linear % NSHARD), t, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// two values at once (the LM kernels reduce a dot product and the q term together)
+__device__ __forceinline__ void block_reduce_atomic2(double v, double w, double* target_v, double* target_w,
+                                                     unsigned wg_linear)
+{
+    __shared__ double wsum2[2][TILE_Y];
+    v = wave_sum(v);
+    w = wave_sum(w);
+    const unsigned lane = threadIdx.x, wave = threadIdx.y;
+    if (lane == 0) { wsum2[0][wave] = v; wsum2[1][wave] = w; }
+    __syncthreads();
+    if (wave == 0 && lane < 2) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < TILE_Y; ++k) t += wsum2[lane][k];
+        if (t != 0.0)
+            __hip_atomic_fetch_add((lane == 0 ? target_v : target_w) + (wg_linear % NSHARD), t, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

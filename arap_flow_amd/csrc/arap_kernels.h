@@ -217,6 +217,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
             ax = ax + wf2 * pO.x;
             ay = ay + wf2 * pO.y;
         }
+        if (pd.lm) {                                   // applyJTJ + CtC*P (o.t:2076-2082)
+            const float2 c = pd.CtCO[v.g];
+            ax = ax + c.x * pO.x;
+            ay = ay + c.y * pO.y;
+            aa = aa + pd.CtCA[v.g] * pA;
+        }
         pd.ApO[v.g] = make_float2(ax, ay);
         pd.ApA[v.g] = aa;
         d = (double)dot3(pO.x, pO.y, pA, ax, ay, aa);
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
     float alpha = 0.f;
     if (sigma > 0.f) alpha = rho / sigma;
     const unsigned f = v.in ? pd.flags[v.g] : 0u;
-    double d = 0.0;
+    double d = 0.0, q = 0.0;
     if (f & F_ACT) {
         const float2 pO = pO_[v.g], ApO = pd.ApO[v.g], mO = pd.preO[v.g];
         const float pA = pA_[v.g], ApA = pd.ApA[v.g], mA = pd.preA[v.g];
@@ -259,8 +265,16 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
         pd.zO[v.g] = make_float2(zx, zy);
         pd.zA[v.g] = za;
         d = (double)dot3(zx, zy, za, rO.x, rO.y, rA);
+        if (pd.lm) {                                   // computeQ (:477-482): q = 0.5 delta.(r + b)
+            const float2 b = pd.bO[v.g];
+            q = (double)(0.5f * dot3(dO.x, dO.y, dA, rO.x + b.x, rO.y + b.y, rA + pd.bA[v.g]));
+        }
     }
-    block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD, v.wg);
+    if (pd.lm)
+        block_reduce_atomic2(d, q, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD,
+                             pd.lmred + (size_t)(l + 1) * NSHARD, v.wg);
+    else
+        block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD, v.wg);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@
 #include "../../include/arap_opt.h"
 #include "arap_kernels.h"
 #include "arap_resident.h"
+#include "arap_lm.h"
 #include "arap_warp.h"
 
 using namespace arap;
@@ -84,7 +85,7 @@ struct Opt_State {
 };
 
 struct Opt_Problem {
-    int kind;    // 0 = gaussNewtonGPU
+    int kind;    // 0 = gaussNewtonGPU, 1 = LMGPU
 };
 
 // solver parameter table and defaults: solverGPUGaussNewton.t:26-39, :148-163
@@ -126,6 +127,15 @@ struct Opt_Plan {
     bool opt_res_ok = false;
     Slot opt_res_slot{};
     int* d_notgrid = nullptr;
+    // "LMGPU" plans
+    int kind = 0;
+    void* lm_block = nullptr;       // b, CtC, SSq, Adelta, prevX
+    float2* prevO = nullptr;
+    float* prevA = nullptr;
+    int lm_lcap = 0;
+    float lm_radius = 0.f, lm_decrease = 0.f;      // pd.parameters.trust_region_radius / radius_decrease_factor
+    double lm_prev_cost = 0.0;
+    bool lm_done = false;
 
     dim3 grid() const { return dim3(pd.tilesX, pd.tilesY, nb); }
     dim3 blk() const { return dim3(TILE_X, TILE_Y, 1); }
@@ -297,6 +307,8 @@ static void plan_free(Opt_Plan* p)
     if (p->pd.costred) (void)hipFree(p->pd.costred);
     if (p->res_block) (void)hipFree(p->res_block);
     if (p->d_notgrid) (void)hipFree(p->d_notgrid);
+    if (p->lm_block) (void)hipFree(p->lm_block);
+    if (p->pd.lmred) (void)hipFree(p->pd.lmred);
     if (p->block) (void)hipFree(p->block);
     delete p;
 }
@@ -485,6 +497,131 @@ static int plan_step(Opt_Plan* p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// "LMGPU": host loop of the Levenberg-Marquardt branch (solverGPUGaussNewton.t:1016-1177 with UsesLambda).
+// Like the reference it is host driven: Q is read back after every PCG iteration for the zeta test (:1093-1102)
+// and the costs after every step (:1119-1157); no graph, one frame (Opt_* plans only).
+// ---------------------------------------------------------------------------------------------
+static void plan_lm_alloc(Opt_Plan* p)
+{
+    if (p->lm_block) return;
+    const size_t N = (size_t)p->N;
+    const size_t sz2 = align_up(N * sizeof(float2), 256), sz1 = align_up(N * sizeof(float), 256);
+    HC(hipMalloc(&p->lm_block, 5 * sz2 + 5 * sz1));
+    HC(hipMemsetAsync(p->lm_block, 0, 5 * sz2 + 5 * sz1, p->st->stream));
+    char* c = (char*)p->lm_block;
+    auto take = [&](size_t s) { char* r = c; c += s; return r; };
+    p->pd.bO = (float2*)take(sz2); p->pd.CtCO = (float2*)take(sz2); p->pd.SSqO = (float2*)take(sz2);
+    p->pd.AdO = (float2*)take(sz2); p->prevO = (float2*)take(sz2);
+    p->pd.bA = (float*)take(sz1); p->pd.CtCA = (float*)take(sz1); p->pd.SSqA = (float*)take(sz1);
+    p->pd.AdA = (float*)take(sz1); p->prevA = (float*)take(sz1);
+}
+
+static double plan_read_shards(Opt_Plan* p, const double* dev)
+{
+    double sh[NSHARD];
+    HC(hipMemcpyAsync(sh, dev, sizeof(sh), hipMemcpyDeviceToHost, p->st->stream));
+    HC(hipStreamSynchronize(p->st->stream));
+    double t = 0.0;
+    for (int i = 0; i < NSHARD; ++i) t += sh[i];
+    return t;
+}
+
+static void plan_init_lm(Opt_Plan* p)
+{
+    HC(hipSetDevice(p->st->device));
+    plan_lm_alloc(p);
+    p->sp.nIter = 0;
+    p->pd.lm = 1;
+    plan_reserve(p, p->sp.lIterations, 2);
+    if (p->sp.lIterations + 2 > p->lm_lcap || !p->pd.lmred) {
+        HC(hipStreamSynchronize(p->st->stream));
+        if (p->pd.lmred) HC(hipFree(p->pd.lmred));
+        p->lm_lcap = p->sp.lIterations + 2;
+        HC(hipMalloc(&p->pd.lmred, (size_t)p->lm_lcap * NSHARD * sizeof(double)));
+    }
+    plan_upload_slots(p);
+    p->lm_radius = p->sp.trust_region_radius;                 // init copies the solver parameters (:996-1001)
+    p->lm_decrease = p->sp.radius_decrease_factor;
+    p->lm_done = false;
+    HC(hipMemsetAsync(p->pd.costred, 0, (size_t)p->pd.ncost * NSHARD * sizeof(double), p->st->stream));
+    hipLaunchKernelGGL(k_cost, p->grid(), p->blk(), 0, p->st->stream, p->pd, 0);
+    p->lm_prev_cost = plan_read_cost(p, 0, 0);
+}
+
+static int plan_step_lm(Opt_Plan* p)
+{
+    Opt_State* st = p->st;
+    hipStream_t s = st->stream;
+    const SolverParameters& sp = p->sp;
+    if (p->lm_done || sp.nIter >= sp.nIterations) return 0;
+    plan_upload_slots(p);
+    const dim3 g = p->grid(), b = p->blk();
+    const int L = sp.lIterations;
+    const size_t N = (size_t)p->N;
+    HC(hipMemsetAsync(p->pd.red, 0, (size_t)p->pd.nslots * NSHARD * sizeof(double), s));
+    HC(hipMemsetAsync(p->pd.lmred, 0, (size_t)p->lm_lcap * NSHARD * sizeof(double), s));
+    hipLaunchKernelGGL(k_gn_prep, g, b, 0, s, p->pd);
+    hipLaunchKernelGGL(k_gn_init, g, b, 0, s, p->pd);
+    HC(hipMemsetAsync(p->pd.red, 0, NSHARD * sizeof(double), s));            // scanAlphaNumerator again (:1041)
+    hipLaunchKernelGGL(k_lm_prepare, g, b, 0, s, p->pd, p->lm_radius, sp.min_lm_diagonal, sp.max_lm_diagonal,
+                       sp.nIter == 0 ? 1 : 0);
+    float Q0 = (float)plan_read_shards(p, p->pd.lmred);
+    for (int l = 0; l < L; ++l) {
+        hipLaunchKernelGGL(k_pcg_a, g, b, 0, s, p->pd, l);
+        if (((l + 1) % sp.residual_reset_period) == 0) {
+            hipLaunchKernelGGL(k_lm_step2a, g, b, 0, s, p->pd, l);
+            hipLaunchKernelGGL(k_lm_apply, g, b, 0, s, p->pd, (const float2*)p->pd.deltaO, (const float*)p->pd.deltaA,
+                               p->pd.AdO, p->pd.AdA);
+            hipLaunchKernelGGL(k_lm_step2b, g, b, 0, s, p->pd, l);
+        } else {
+            hipLaunchKernelGGL(k_pcg_b, g, b, 0, s, p->pd, l);
+        }
+        const float Q1 = (float)plan_read_shards(p, p->pd.lmred + (size_t)(l + 1) * NSHARD);
+        const float zeta = (float)(l + 1) * (Q1 - Q0) / Q1;
+        if (zeta < sp.q_tolerance) break;
+        Q0 = Q1;
+    }
+    hipLaunchKernelGGL(k_lm_model_cost, g, b, 0, s, p->pd, p->lm_lcap - 1);
+    const float model_cost = (float)plan_read_shards(p, p->pd.lmred + (size_t)(p->lm_lcap - 1) * NSHARD);
+    const float model_cost_change = (float)p->lm_prev_cost - model_cost;
+    const Slot& sl = p->hslots[0];
+    HC(hipMemcpyAsync(p->prevO, sl.O, N * sizeof(float2), hipMemcpyDeviceToDevice, s));   // savePreviousUnknowns
+    HC(hipMemcpyAsync(p->prevA, sl.A, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_gn_update, g, b, 0, s, p->pd);
+    HC(hipMemsetAsync(p->pd.costred + NSHARD, 0, NSHARD * sizeof(double), s));
+    hipLaunchKernelGGL(k_cost, g, b, 0, s, p->pd, 1);
+    const double newCost = plan_read_cost(p, 0, 1);
+    const float cost_change = (float)p->lm_prev_cost - (float)newCost;
+    const float relative_decrease = cost_change / model_cost_change;
+    if (cost_change >= 0 && relative_decrease > sp.min_relative_decrease) {
+        if (cost_change <= (float)p->lm_prev_cost * sp.function_tolerance) {
+            if (st->verbosity > 0) printf("\nFunction tolerance reached, exiting\n");
+            p->lm_done = true;
+            return 0;
+        }
+        const double step_quality = relative_decrease;
+        const double tmp_factor = 1.0 - pow(2.0 * step_quality - 1.0, 3.0);
+        p->lm_radius = (float)((double)p->lm_radius / fmax(1.0 / 3.0, tmp_factor));
+        p->lm_radius = (float)fmin((double)p->lm_radius, (double)sp.max_trust_region_radius);
+        p->lm_decrease = 2.0f;
+        p->lm_prev_cost = newCost;
+    } else {
+        HC(hipMemcpyAsync(sl.O, p->prevO, N * sizeof(float2), hipMemcpyDeviceToDevice, s));   // revertUpdate
+        HC(hipMemcpyAsync(sl.A, p->prevA, N * sizeof(float), hipMemcpyDeviceToDevice, s));
+        p->lm_radius = p->lm_radius / p->lm_decrease;
+        p->lm_decrease = 2.0f * p->lm_decrease;
+        if (p->lm_radius <= sp.min_trust_region_radius) {
+            if (st->verbosity > 0) printf("\nTrust_region_radius is less than the min, exiting\n");
+            p->lm_done = true;
+            return 0;
+        }
+    }
+    if (st->verbosity > 0) printf("cost: %f (trust_region_radius %g)\n", p->lm_prev_cost, p->lm_radius);
+    p->sp.nIter += 1;
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Problem specification check.  The library hard-codes the energy of arap_plan.t:1-23; the file
 // named in Opt_ProblemDefine is checked declaration by declaration against it.
 // ---------------------------------------------------------------------------------------------
@@ -582,11 +719,9 @@ void ArapFlow_FreeState(Opt_State* st)
 Opt_Problem* Opt_ProblemDefine(Opt_State* state, const char* filename, const char* solverkind)
 {
     if (!state || !filename || !solverkind) return nullptr;
-    if (strcmp(solverkind, "gaussNewtonGPU") != 0) {
-        if (strcmp(solverkind, "LMGPU") == 0)
-            fprintf(stderr, "arapopt: solver kind LMGPU is not implemented (only gaussNewtonGPU)\n");
-        else
-            fprintf(stderr, "arapopt: unknown solver kind '%s' (expected gaussNewtonGPU)\n", solverkind);
+    const int kind = strcmp(solverkind, "gaussNewtonGPU") == 0 ? 0 : (strcmp(solverkind, "LMGPU") == 0 ? 1 : -1);
+    if (kind < 0) {                                                       // asserted at o.t:122
+        fprintf(stderr, "arapopt: unknown solver kind '%s' (expected gaussNewtonGPU or LMGPU)\n", solverkind);
         return nullptr;
     }
     if (strcmp(filename, "builtin:arap") != 0) {
@@ -609,7 +744,7 @@ Opt_Problem* Opt_ProblemDefine(Opt_State* state, const char* filename, const cha
         }
     }
     Opt_Problem* pr = new Opt_Problem();
-    pr->kind = 0;
+    pr->kind = kind;
     if (state->verbosity > 1) printf("arapopt: problem '%s' (%s) accepted\n", filename, solverkind);
     return pr;
 }
@@ -625,7 +760,8 @@ Opt_Plan* Opt_ProblemPlan(Opt_State* state, Opt_Problem* problem, unsigned int* 
         return nullptr;
     }
     Opt_Plan* p = plan_create(state, (int)W, (int)H, 1);
-    plan_enable_resident(p);
+    p->kind = problem->kind;
+    if (p->kind == 0) plan_enable_resident(p);
     return p;
 }
 
@@ -650,13 +786,13 @@ void Opt_ProblemInit(Opt_State*, Opt_Plan* plan, void** problemparams)
 {
     plan->nb = 1;
     slot_from_params(plan->hslots[0], problemparams);
-    plan_init(plan);
+    if (plan->kind == 1) plan_init_lm(plan); else plan_init(plan);
 }
 
 int Opt_ProblemStep(Opt_State*, Opt_Plan* plan, void** problemparams)
 {
     slot_from_params(plan->hslots[0], problemparams);
-    return plan_step(plan);
+    return plan->kind == 1 ? plan_step_lm(plan) : plan_step(plan);
 }
 
 void Opt_ProblemSolve(Opt_State* state, Opt_Plan* plan, void** problemparams)
@@ -667,6 +803,7 @@ void Opt_ProblemSolve(Opt_State* state, Opt_Plan* plan, void** problemparams)
 
 double Opt_ProblemCurrentCost(Opt_State*, Opt_Plan* plan)
 {
+    if (plan->kind == 1) return (double)(float)plan->lm_prev_cost;
     return plan_read_cost(plan, 0, plan->sp.nIter);
 }
 

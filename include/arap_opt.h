@@ -57,8 +57,9 @@ Opt_State* Opt_NewState(Opt_InitializationParameters params);
  * white space, and its declarations are checked against that energy.  Anything else prints a
  * diagnostic and returns NULL (the reference returns NULL from Opt_ProblemPlan when compilation
  * fails, o.t:861-881).  The literal name "builtin:arap" selects the energy without a file.
- * `solverkind`: "gaussNewtonGPU" (what the application uses, CombinedSolverBase.h:75-77);
- * "LMGPU" is not implemented: diagnostic + NULL. */
+ * `solverkind`: "gaussNewtonGPU" (what the application uses, CombinedSolverBase.h:75-77) or "LMGPU" (the
+ * Levenberg-Marquardt branch of the same solver, solverGPUGaussNewton.t:615-680,1038-1157: trust region, CtC,
+ * model cost, revert); anything else: diagnostic + NULL (asserted at o.t:122). */
 Opt_Problem* Opt_ProblemDefine(Opt_State* state, const char* filename, const char* solverkind);
 void Opt_ProblemDelete(Opt_State* state, Opt_Problem* problem);
 
@@ -68,8 +69,8 @@ Opt_Plan* Opt_ProblemPlan(Opt_State* state, Opt_Problem* problem, unsigned int* 
 void Opt_PlanFree(Opt_State* state, Opt_Plan* plan);
 
 /* Opt.h:51.  `value` points to an int for "nIterations", "lIterations", "residual_reset_period"
- * and to a float for the nine LM parameters (solverGPUGaussNewton.t:148-163); the LM ones are
- * stored and otherwise unused on the Gauss-Newton path.  Unknown names print a warning (:1220). */
+ * and to a float for the nine LM parameters (solverGPUGaussNewton.t:148-163), which only "LMGPU" plans read.
+ * Unknown names print a warning (:1220). */
 void Opt_SetSolverParameter(Opt_State* state, Opt_Plan* plan, const char* name, void* value);
 
 /* Opt.h:56-66.  problemparams is indexed by the plan's declared indices (arap_plan.t:2-8,

@@ -422,6 +422,191 @@ double FN(oracle_solve)(int W, int H, REAL *O, REAL *A, const REAL *U, const REA
     return c;
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * "LMGPU" solver kind of the same API: the Levenberg-Marquardt branch of
+ * solverGPUGaussNewton.t (UsesLambda): PCGSaveSSq :622-627, PCGComputeCtC :616-621 with computeCtC =
+ * diag(J^T J)/trust_region_radius (o.t:2255-2287), PCGFinalizeDiagonal :629-662, applyJTJ + CtC*P
+ * (o.t:2076-2082), PCGStep2 with q :477-482, residual reset :491-535 (PCGStep2_1stHalf, computeAdelta,
+ * PCGStep2_2ndHalf), zeta break :1093-1102, model cost (o.t:2180-2201, :665-678), accept/reject and trust
+ * region update :1119-1157.  The application never selects it (CombinedSolverBase.h:75-77) and the reference
+ * holds no LM output: parity of this branch is pinned to this restatement only ("parity unpinned").
+ * lm[9] = min_relative_decrease, min_trust_region_radius, max_trust_region_radius, q_tolerance,
+ *         function_tolerance, trust_region_radius, radius_decrease_factor, min_lm_diagonal, max_lm_diagonal
+ * Returns the number of steps taken; costs[0..steps] as for the GN solve; *final_radius out. */
+static REAL FN(clampr)(REAL x, REAL lo, REAL hi) { REAL m = x > lo ? x : lo; return m < hi ? m : hi; }
+
+static void FN(apply_lm_at)(const FN(Prob) * pb, const REAL *cs, const REAL *CtC, const REAL *P, int x, int y, REAL out[3])
+{
+    size_t i = (size_t)(x + pb->W * y);
+    FN(applyJTJ_at)(pb, cs, P, x, y, out);
+    for (int k = 0; k < 3; ++k) out[k] = out[k] + CtC[3 * i + k] * P[3 * i + k];
+}
+
+int FN(oracle_solve_lm)(int W, int H, REAL *O, REAL *A, const REAL *U, const REAL *C, const REAL *M, REAL wf,
+                        REAL wr, int nIterations, int lIterations, int residual_reset_period, const REAL *lm,
+                        int trig, double *costs, REAL *final_radius)
+{
+    FN(Prob) pbv = {W, H, U, C, M, wf, wr, trig};
+    const FN(Prob) *pb = &pbv;
+    const size_t N = (size_t)W * H;
+    FN(Plan) plv; FN(Plan) *pl = &plv;
+    FN(plan_alloc)(pl, N);
+    REAL *b = (REAL *)calloc(3 * N, sizeof(REAL)), *CtC = (REAL *)calloc(3 * N, sizeof(REAL));
+    REAL *SSq = (REAL *)calloc(3 * N, sizeof(REAL)), *Ad = (REAL *)calloc(3 * N, sizeof(REAL));
+    REAL *pO = (REAL *)malloc(2 * N * sizeof(REAL)), *pA = (REAL *)malloc(N * sizeof(REAL));
+    const REAL min_rel = lm[0], min_rad = lm[1], max_rad = lm[2], q_tol = lm[3], f_tol = lm[4];
+    REAL radius = lm[5], dec = lm[6];
+    const REAL min_diag = lm[7], max_diag = lm[8];
+    const int mode = 1;
+    double prevCost = FN(cost_)(pb, O, A, mode);
+    costs[0] = prevCost;
+    int steps = 0;
+    for (int nIter = 0; nIter < nIterations; ++nIter) {
+        FN(fill_cs)(pb, A, pl->cs);
+        double sd = 0.0, sq = 0.0;
+        const REAL inv_radius = (REAL)1 / radius;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)(x + W * y);
+                if (!FN(act)(pb, (int)i)) continue;
+                REAL g[3], d[3];
+                FN(evalJTF_at)(pb, O, A, x, y, g, d);
+                for (int k = 0; k < 3; ++k) {
+                    pl->delta[3 * i + k] = 0;
+                    pl->r[3 * i + k] = -g[k];
+                    pl->pre[3 * i + k] = FN(ginv)(d[k]);                       /* PCGInit1 */
+                    if (nIter == 0) SSq[3 * i + k] = pl->pre[3 * i + k];      /* PCGSaveSSq, ONCE_PER_SOLVE */
+                    const REAL unclamped = d[k] * inv_radius;                  /* PCGComputeCtC */
+                    const REAL mult = ((REAL)1 / SSq[3 * i + k]) / radius;     /* PCGFinalizeDiagonal */
+                    const REAL ctc = FN(clampr)(unclamped, min_diag * mult, max_diag * mult);
+                    CtC[3 * i + k] = ctc;
+                    pl->pre[3 * i + k] = (REAL)1 / (ctc + radius * unclamped);
+                    b[3 * i + k] = pl->r[3 * i + k];
+                    pl->p[3 * i + k] = pl->pre[3 * i + k] * pl->r[3 * i + k];
+                }
+                sd += (double)FN(dot3)(pl->r + 3 * i, pl->p + 3 * i);
+                {   REAL rr[3]; for (int k = 0; k < 3; ++k) rr[k] = pl->r[3 * i + k] + pl->r[3 * i + k];
+                    sq += (double)((REAL)0.5 * FN(dot3)(pl->delta + 3 * i, rr)); }
+            }
+        REAL rho = (REAL)sd, Q0 = (REAL)sq;
+        for (int l = 0; l < lIterations; ++l) {
+            sd = 0.0;
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    size_t i = (size_t)(x + W * y);
+                    if (!FN(act)(pb, (int)i)) continue;
+                    FN(apply_lm_at)(pb, pl->cs, CtC, pl->p, x, y, pl->Ap + 3 * i);
+                    sd += (double)FN(dot3)(pl->p + 3 * i, pl->Ap + 3 * i);
+                }
+            const REAL sigma = (REAL)sd;
+            REAL alpha = 0;
+            if (sigma > (REAL)0) alpha = rho / sigma;
+            sd = 0.0; sq = 0.0;
+            if (((l + 1) % residual_reset_period) == 0) {
+                for (size_t i = 0; i < N; ++i) {                               /* PCGStep2_1stHalf */
+                    if (!FN(act)(pb, (int)i)) continue;
+                    for (int k = 0; k < 3; ++k) pl->delta[3 * i + k] = pl->delta[3 * i + k] + alpha * pl->p[3 * i + k];
+                }
+                for (int y = 0; y < H; ++y)                                    /* computeAdelta */
+                    for (int x = 0; x < W; ++x) {
+                        size_t i = (size_t)(x + W * y);
+                        if (FN(act)(pb, (int)i)) FN(apply_lm_at)(pb, pl->cs, CtC, pl->delta, x, y, Ad + 3 * i);
+                    }
+                for (size_t i = 0; i < N; ++i) {                               /* PCGStep2_2ndHalf */
+                    if (!FN(act)(pb, (int)i)) continue;
+                    REAL rb[3];
+                    for (int k = 0; k < 3; ++k) {
+                        pl->r[3 * i + k] = b[3 * i + k] - Ad[3 * i + k];
+                        pl->z[3 * i + k] = pl->pre[3 * i + k] * pl->r[3 * i + k];
+                        rb[k] = pl->r[3 * i + k] + b[3 * i + k];
+                    }
+                    sd += (double)FN(dot3)(pl->z + 3 * i, pl->r + 3 * i);
+                    sq += (double)((REAL)0.5 * FN(dot3)(pl->delta + 3 * i, rb));
+                }
+            } else {
+                for (size_t i = 0; i < N; ++i) {                               /* PCGStep2 with q */
+                    if (!FN(act)(pb, (int)i)) continue;
+                    REAL rb[3];
+                    for (int k = 0; k < 3; ++k) {
+                        pl->delta[3 * i + k] = pl->delta[3 * i + k] + alpha * pl->p[3 * i + k];
+                        pl->r[3 * i + k] = pl->r[3 * i + k] - alpha * pl->Ap[3 * i + k];
+                        pl->z[3 * i + k] = pl->pre[3 * i + k] * pl->r[3 * i + k];
+                        rb[k] = pl->r[3 * i + k] + b[3 * i + k];
+                    }
+                    sd += (double)FN(dot3)(pl->z + 3 * i, pl->r + 3 * i);
+                    sq += (double)((REAL)0.5 * FN(dot3)(pl->delta + 3 * i, rb));
+                }
+            }
+            const REAL rhoNew = (REAL)sd;
+            REAL beta = 0;
+            if (rho > (REAL)0) beta = rhoNew / rho;
+            for (size_t i = 0; i < N; ++i) {
+                if (!FN(act)(pb, (int)i)) continue;
+                for (int k = 0; k < 3; ++k) pl->p[3 * i + k] = pl->z[3 * i + k] + beta * pl->p[3 * i + k];
+            }
+            rho = rhoNew;
+            const REAL Q1 = (REAL)sq;
+            const REAL zeta = (REAL)(l + 1) * (Q1 - Q0) / Q1;
+            if (zeta < q_tol) break;
+            Q0 = Q1;
+        }
+        /* model cost: 0.5 * sum (F + J delta)^2 over the residuals centred on active vertices */
+        double mc = 0.0;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                size_t i = (size_t)(x + W * y);
+                int n;
+                if (!FN(act)(pb, (int)i)) continue;
+                REAL e[10];
+                FN(residuals_at)(pb, O, A, x, y, e);
+                const REAL ci = pl->cs[2 * i], si = pl->cs[2 * i + 1];
+                REAL t = 0;
+                for (int k = 0; k < 4; ++k) {
+                    if (!FN(edge)(pb, x, y, k, &n)) continue;
+                    REAL dx = U[2 * i] - U[2 * n], dy = U[2 * i + 1] - U[2 * n + 1];
+                    REAL qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
+                    REAL mx = e[2 * k] + wr * ((pl->delta[3 * i] - pl->delta[3 * n]) - qx * pl->delta[3 * i + 2]);
+                    REAL my = e[2 * k + 1] + wr * ((pl->delta[3 * i + 1] - pl->delta[3 * n + 1]) - qy * pl->delta[3 * i + 2]);
+                    t = t + mx * mx; t = t + my * my;
+                }
+                if (FN(fit)(pb, (int)i)) {
+                    REAL mx = e[8] + wf * pl->delta[3 * i], my = e[9] + wf * pl->delta[3 * i + 1];
+                    t = t + mx * mx; t = t + my * my;
+                }
+                mc += (double)((REAL)0.5 * t);
+            }
+        const REAL model_cost_change = (REAL)prevCost - (REAL)mc;
+        memcpy(pO, O, 2 * N * sizeof(REAL)); memcpy(pA, A, N * sizeof(REAL));      /* savePreviousUnknowns */
+        for (size_t i = 0; i < N; ++i) {
+            if (!FN(act)(pb, (int)i)) continue;
+            O[2 * i] = O[2 * i] + pl->delta[3 * i]; O[2 * i + 1] = O[2 * i + 1] + pl->delta[3 * i + 1];
+            A[i] = A[i] + pl->delta[3 * i + 2];
+        }
+        const double newCost = FN(cost_)(pb, O, A, mode);
+        const REAL cost_change = (REAL)prevCost - (REAL)newCost;
+        const REAL relative_decrease = cost_change / model_cost_change;
+        ++steps;
+        if (cost_change >= 0 && relative_decrease > min_rel) {
+            if (cost_change <= (REAL)prevCost * f_tol) { costs[steps] = prevCost; --steps; break; }   /* exits, cost stays */
+            const double sqv = (double)relative_decrease, tmp = 1.0 - pow(2.0 * sqv - 1.0, 3.0);
+            radius = (REAL)((double)radius / fmax(1.0 / 3.0, tmp));
+            radius = (REAL)fmin((double)radius, (double)max_rad);
+            dec = (REAL)2;
+            prevCost = newCost;
+        } else {
+            memcpy(O, pO, 2 * N * sizeof(REAL)); memcpy(A, pA, N * sizeof(REAL)); /* revertUpdate */
+            radius = radius / dec;
+            dec = (REAL)2 * dec;
+            if (radius <= min_rad) { costs[steps] = prevCost; --steps; break; }
+        }
+        costs[steps] = prevCost;
+    }
+    *final_radius = radius;
+    FN(plan_free)(pl);
+    free(b); free(CtC); free(SSq); free(Ad); free(pO); free(pA);
+    return steps;
+}
+
 /* setConstraintImage(alpha): ARAP/deformation/src/CombinedSolver.h:223-242.  float arithmetic in
  * the reference regardless of solver precision: computed in float, then widened. */
 static void FN(constraint_image)(int W, int H, const unsigned char *mask_red, const int *cons, int ncons,

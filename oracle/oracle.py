@@ -111,6 +111,31 @@ def solve(O, A, U, Cn, M, wf, wr, nIterations, lIterations, dtype=np.float32, mo
     return O, A, costs
 
 
+LM_DEFAULTS = dict(min_relative_decrease=1e-3, min_trust_region_radius=1e-32, max_trust_region_radius=1e16,
+                   q_tolerance=1e-4, function_tolerance=1e-6, trust_region_radius=1e4, radius_decrease_factor=2.0,
+                   min_lm_diagonal=1e-6, max_lm_diagonal=1e32)      # solverGPUGaussNewton.t:26-39
+
+
+def solve_lm(O, A, U, Cn, M, wf, wr, nIterations, lIterations, residual_reset_period=10, dtype=np.float32, trig=1,
+             **lm):
+    """One Opt_ProblemSolve with solver kind "LMGPU".  Returns (O, A, costs[0..steps], steps, final radius)."""
+    H, W = A.shape
+    O, A, U, Cn, M = _prep(dtype, O, A, U, Cn, M)
+    O, A = O.copy(), A.copy()
+    pars = dict(LM_DEFAULTS); pars.update(lm)
+    order = ["min_relative_decrease", "min_trust_region_radius", "max_trust_region_radius", "q_tolerance",
+             "function_tolerance", "trust_region_radius", "radius_decrease_factor", "min_lm_diagonal", "max_lm_diagonal"]
+    lmv = np.asarray([pars[k] for k in order], dtype)
+    costs = np.zeros(nIterations + 2, np.float64)
+    rad = np.zeros(1, dtype)
+    f = getattr(lib(), "oracle_solve_lm" + _suf(dtype))
+    f.restype = C.c_int
+    steps = f(C.c_int(W), C.c_int(H), _p(O), _p(A), _p(U), _p(Cn), _p(M), _ct(dtype)(wf), _ct(dtype)(wr),
+              C.c_int(nIterations), C.c_int(lIterations), C.c_int(residual_reset_period), _p(lmv), C.c_int(trig),
+              _p(costs), _p(rad))
+    return O, A, costs[:steps + 1], steps, float(rad[0])
+
+
 def frame(mask_red, cons, numIter=19, nIterations=8, lIterations=400, dtype=np.float32, mode=1, trig=0,
           border_pins=True):
     """Full arap_deform schedule for one frame.  mask_red u8[H,W]; cons int[n,4].

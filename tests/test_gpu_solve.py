@@ -79,7 +79,9 @@ def test_opt_init_step_protocol(gpu_state, oracle):
 
 def test_problem_define_accepts_only_the_arap_energy(gpu_state, tmp_path):
     lib, st = gpu_state.lib, gpu_state.handle
-    assert lib.Opt_ProblemDefine(st, b"builtin:arap", b"LMGPU") is None            # not implemented: NULL
+    p_lm = lib.Opt_ProblemDefine(st, b"builtin:arap", b"LMGPU")                     # the other kind of o.t:122
+    assert p_lm is not None
+    lib.Opt_ProblemDelete(st, p_lm)
     assert lib.Opt_ProblemDefine(st, b"builtin:arap", b"bogus") is None
     assert lib.Opt_ProblemDefine(st, str(tmp_path / "missing.t").encode(), b"gaussNewtonGPU") is None
     bad = tmp_path / "other.t"
@@ -260,3 +262,30 @@ def test_drop_in_api_takes_resident_kernel_only_for_grid_urshape(gpu_state, orac
                                      mode=1, trig=1)
         assert np.array_equal(dev["O"].cpu().numpy(), Or) and np.array_equal(dev["A"].cpu().numpy(), Ar)
         assert cost == costs[-1]
+
+
+@pytest.mark.parametrize("W,H,nIter,lIter,radius", [(64, 48, 4, 25, 1e4), (130, 37, 6, 40, 1e4), (90, 70, 5, 30, 1e-3)])
+def test_LM_solver_kind_vs_oracle(gpu_state, oracle, W, H, nIter, lIter, radius):
+    """Solver kind "LMGPU"  through Opt_ProblemSolve vs the CPU restatement of the same branch:
+    trust-region bookkeeping (accept / reject / revert), CtC, model cost, zeta break, residual reset every 10th
+    iteration.  The reference holds no LM output, so this parity is pinned to the restatement only."""
+    pb = helpers.random_problem(W, H, seed=W * 3 + H, generic_urshape=(W % 2 == 0), ncons=max(6, W * H // 50))
+    dev = {k: torch.from_numpy(pb[k].copy()).cuda() for k in "OAUCM"}
+    s = opt.OptSolver(gpu_state, (W, H), opt.BUILTIN_PLAN, b"LMGPU")
+    pp = opt.NamedParameters()
+    for n, k in [("Offset", "O"), ("Angle", "A"), ("UrShape", "U"), ("Constraints", "C"), ("Mask", "M")]:
+        pp.set(n, dev[k])
+    pp.set("w_fitSqrt", 10.0); pp.set("w_regSqrt", 0.1)
+    sp = opt.NamedParameters()
+    sp.set("nIterations", nIter); sp.set("lIterations", lIter); sp.set("trust_region_radius", float(radius))
+    cost = s.solve(sp, pp)
+    s.close()
+    Or, Ar, costs, steps, rad = oracle.solve_lm(pb["O"], pb["A"], pb["U"], pb["C"], pb["M"], 10.0, 0.1, nIter, lIter,
+                                                trust_region_radius=radius)
+    dO, dOr = dev["O"].cpu().numpy() - pb["O"], Or - pb["O"]
+    assert helpers.rel_l2(dO, dOr) < 1e-4 and helpers.rel_l2(dev["A"].cpu().numpy() - pb["A"], Ar - pb["A"]) < 1e-4
+    assert abs(cost - costs[-1]) <= 1e-4 * abs(costs[-1])
+    assert costs[-1] < costs[0]                                       # LM made progress
+    ex = pb["M"] != 0
+    assert np.array_equal(dev["O"].cpu().numpy()[ex], pb["O"][ex])
+    print("LM %dx%d: %d steps, final radius %g, mismatching floats %d" % (W, H, steps, rad, int((dO != dOr).sum())))
