@@ -112,7 +112,7 @@ struct Opt_Plan {
     // graph of one GN step, keyed by (lIterations, nb)
     hipGraphExec_t gexec = nullptr;
     hipGraph_t graph = nullptr;
-    int g_l = -1, g_nb = -1, g_res = -1;
+    int g_l = -1, g_nb = -1, g_res = -1;   // g_res: 0 = two-kernel path, else the resident group count
     double prevCost[1] = {0.0};
     bool cost_valid = false;
     int cost_index = 0;
@@ -419,7 +419,8 @@ static void plan_gn_step(Opt_Plan* p)
         enqueue_gn_step(p, st->stream);
         return;
     }
-    const int res_now = plan_resident_eligible(p) ? 1 : 0;
+    // the captured resident launches bake in the group count, which follows the frames' active-tile counts
+    const int res_now = plan_resident_eligible(p) ? plan_resident_groups(p) : 0;
     if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));

@@ -289,3 +289,56 @@ def test_LM_solver_kind_vs_oracle(gpu_state, oracle, W, H, nIter, lIter, radius)
     ex = pb["M"] != 0
     assert np.array_equal(dev["O"].cpu().numpy()[ex], pb["O"][ex])
     print("LM %dx%d: %d steps, final radius %g, mismatching floats %d" % (W, H, steps, rad, int((dO != dOr).sum())))
+
+
+def test_solver_reuse_across_frames_of_different_tile_counts(gpu_state):
+    """One FrameSolver fed small frames (16 resident groups), then a large one (fewer, wider groups), then small
+    again: the cached hipGraph must follow the group count.  Each result equals a fresh solver's."""
+    from arap_flow_amd import synth
+    W, H = 854, 480
+    small = synth.make_frame(W, H, seed=31, K=3, fd=2)
+    segs = synth.segment_masks(small)                       # ~35 k active vertices each
+    big = synth.make_frame(W, H, seed=32, full_mask=True)   # 1680 tiles
+    sched = (1, 2, 30)
+    fs = opt.FrameSolver(gpu_state, W, H, batch=3)
+    got = []
+    for rnd in range(3):
+        frames = [big] if rnd == 1 else segs
+        for b, f in enumerate(frames):
+            fs.set_frame(b, f["mask_red"], f["constraints"])
+        fs.solve(len(frames), *sched)
+        got.append([fs.results(b, want_rgb=False)["offset"] for b in range(len(frames))])
+    fs.close()
+    for rnd in range(3):
+        frames = [big] if rnd == 1 else segs
+        for b, f in enumerate(frames):
+            one = opt.FrameSolver(gpu_state, W, H, batch=1)
+            one.set_frame(0, f["mask_red"], f["constraints"])
+            one.solve(1, *sched)
+            assert np.array_equal(one.results(0, want_rgb=False)["offset"], got[rnd][b])
+            one.close()
+
+
+def test_frame_edge_cases_empty_mask_and_no_constraints(gpu_state, oracle):
+    """a frame whose mask excludes every vertex (nothing to solve, flow stays 0), a frame without any file
+    constraint (only the border pins act) and a batch mixing them with a normal frame"""
+    from arap_flow_amd import synth
+    W, H = 100, 60
+    normal = synth.make_frame(W, H, seed=8)
+    none_active = np.full((H, W), 255, np.uint8)
+    all_active = np.zeros((H, W), np.uint8)
+    empty = np.zeros((0, 4), np.int32)
+    fs = opt.FrameSolver(gpu_state, W, H, batch=3)
+    fs.set_frame(0, none_active, normal["constraints"], rgb=normal["rgb"])
+    fs.set_frame(1, all_active, empty, rgb=normal["rgb"])
+    fs.set_frame(2, normal["mask_red"], normal["constraints"], rgb=normal["rgb"])
+    fs.solve(3, 2, 2, 40)
+    fs.warp(3)
+    r = [fs.results(b) for b in range(3)]
+    fs.close()
+    assert np.all(r[0]["flow"] == 0) and np.all(r[0]["warped_mask"] == 0) and r[0]["cost"] == 0.0
+    assert np.all(r[1]["flow"] == 0) and r[1]["cost"] == 0.0        # pinned border, rest state is the optimum
+    assert np.array_equal(r[1]["warped_rgb"][:-1, :-1], normal["rgb"][:-1, :-1])
+    O, A, costs = oracle.frame(normal["mask_red"], normal["constraints"], numIter=2, nIterations=2, lIterations=40,
+                               dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(r[2]["offset"], O)
