@@ -47,6 +47,7 @@ SYMBOLS = [
     ("ArapFlow_SolverGetResults", _I, [_VP, _U, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_double)]),
     ("ArapFlow_SolverStats", _I, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("ArapFlow_SetResident", None, [_VP, _I]),
+    ("ArapFlow_SetTile", _I, [_VP, _I, _I]),
     ("ArapFlow_SolverResidentLaunches", C.c_uint64, [_VP]),
     ("ArapFlow_PlanResidentLaunches", C.c_uint64, [_VP]),
     ("ArapFlow_SolverStamps", _I, [_VP, _VP]),

@@ -167,7 +167,7 @@ __device__ __forceinline__ void block_reduce_atomic2(double v, double w, double*
 // sum of the NSHARD shards of one scalar, by every wavefront for itself (lanes >= NSHARD add 0)
 __device__ __forceinline__ float read_scalar(const double* shards)
 {
-    const unsigned lane = threadIdx.x & 63u;
+    const unsigned lane = __lane_id();          // true lane: block shapes narrower than 64 put several rows in a wave
     double v = lane < (unsigned)NSHARD
                    ? __hip_atomic_load(shards + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                    : 0.0;

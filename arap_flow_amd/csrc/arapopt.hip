@@ -24,6 +24,7 @@
 #include "arap_kernels.h"
 #include "arap_resident.h"
 #include "arap_lm.h"
+#include "arap_tiled.h"
 #include "arap_warp.h"
 
 using namespace arap;
@@ -82,6 +83,7 @@ struct Opt_State {
     KernelTimer ktimer;
     bool use_graph = true;
     bool use_resident = true;   // ArapFlow_SetResident
+    int tile = 0;               // ArapFlow_SetTile: phase-A variant of the two-kernel path (0 = direct loads)
 };
 
 struct Opt_Problem {
@@ -376,6 +378,27 @@ static void plan_upload_slots(Opt_Plan* p)
         }                                                                                   \
     } while (0)
 
+// phase A of the two-kernel path: direct-load kernel or an LDS-staged tile shape (ArapFlow_SetTile)
+static const int kTileShapes[6][2] = {{0, 0}, {16, 16}, {32, 8}, {64, 4}, {32, 16}, {64, 8}};
+
+static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
+{
+    const int v = p->st->tile;
+    if (v == 0) {
+        LAUNCH(p, s, "PCGStepA", k_pcg_a, p->grid(), p->blk(), p->pd, l);
+        return;
+    }
+    const int TX = kTileShapes[v][0], TY = kTileShapes[v][1];
+    const dim3 g((p->W + TX - 1) / TX, (p->H + TY - 1) / TY, p->nb), b(TX, TY, 1);
+    switch (v) {
+    case 1: LAUNCH(p, s, "PCGStepA", (k_pcg_a_lds<16, 16>), g, b, p->pd, l); break;
+    case 2: LAUNCH(p, s, "PCGStepA", (k_pcg_a_lds<32, 8>), g, b, p->pd, l); break;
+    case 3: LAUNCH(p, s, "PCGStepA", (k_pcg_a_lds<64, 4>), g, b, p->pd, l); break;
+    case 4: LAUNCH(p, s, "PCGStepA", (k_pcg_a_lds<32, 16>), g, b, p->pd, l); break;
+    default: LAUNCH(p, s, "PCGStepA", (k_pcg_a_lds<64, 8>), g, b, p->pd, l); break;
+    }
+}
+
 // enqueue the kernels of one Gauss-Newton step (without the cost) on stream s
 static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
 {
@@ -404,7 +427,7 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
         }
     } else {
         for (int l = 0; l < L; ++l) {
-            LAUNCH(p, s, "PCGStepA", k_pcg_a, g, b, p->pd, l);
+            launch_pcg_a(p, s, l);
             LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
         }
     }
@@ -420,7 +443,7 @@ static void plan_gn_step(Opt_Plan* p)
         return;
     }
     // the captured resident launches bake in the group count, which follows the frames' active-tile counts
-    const int res_now = plan_resident_eligible(p) ? plan_resident_groups(p) : 0;
+    const int res_now = plan_resident_eligible(p) ? plan_resident_groups(p) : -(1 + p->st->tile);
     if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
@@ -814,6 +837,13 @@ double Opt_ProblemCurrentCost(Opt_State*, Opt_Plan* plan)
 const char* ArapFlow_Version(void) { return ARAPOPT_VERSION; }
 
 void ArapFlow_SetResident(Opt_State* state, int on) { state->use_resident = on != 0; }
+
+int ArapFlow_SetTile(Opt_State* state, int tile_x, int tile_y)
+{
+    for (int v = 0; v < 6; ++v)
+        if (kTileShapes[v][0] == tile_x && kTileShapes[v][1] == tile_y) { state->tile = v; return 0; }
+    return -1;
+}
 
 void ArapFlow_SetKernelTiming(Opt_State* state, int on)
 {

@@ -52,6 +52,11 @@ class State:
         """allow (default) / forbid the on-chip resident PCG kernel of the frame solver"""
         self.lib.ArapFlow_SetResident(self.handle, int(bool(on)))
 
+    def set_tile(self, tx, ty):
+        """phase-A variant of the two-kernel path: (0, 0) direct loads, or an LDS tile shape"""
+        if self.lib.ArapFlow_SetTile(self.handle, int(tx), int(ty)) != 0:
+            raise ValueError("unsupported tile %dx%d" % (tx, ty))
+
     def set_kernel_timing(self, on):
         self.lib.ArapFlow_SetKernelTiming(self.handle, int(bool(on)))
 

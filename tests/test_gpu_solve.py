@@ -342,3 +342,31 @@ def test_frame_edge_cases_empty_mask_and_no_constraints(gpu_state, oracle):
     O, A, costs = oracle.frame(normal["mask_red"], normal["constraints"], numIter=2, nIterations=2, lIterations=40,
                                dtype=np.float32, mode=1, trig=1)
     assert np.array_equal(r[2]["offset"], O)
+
+
+@pytest.mark.parametrize("tile", [(16, 16), (32, 8), (64, 4), (32, 16), (64, 8)])
+def test_lds_tiled_phase_a_is_bit_identical(gpu_state, oracle, tile):
+    """two-kernel path with an LDS-staged phase A (BASELINE config 5's tile shapes): same bits as the oracle, for a
+    generic UrShape (Opt_* path) and for a batch of frames whose size is not a multiple of the tile"""
+    from arap_flow_amd import synth
+    gpu_state.set_resident(False)
+    gpu_state.set_tile(*tile)
+    try:
+        W, H = 149, 83
+        pb = helpers.random_problem(W, H, seed=5, generic_urshape=True, ncons=50)
+        O, A, cost = _solve_opt(gpu_state, pb, 2, 30)
+        Or, Ar, costs = oracle.solve(pb["O"], pb["A"], pb["U"], pb["C"], pb["M"], pb["wf"], pb["wr"], 2, 30,
+                                     dtype=np.float32, mode=1, trig=1)
+        assert np.array_equal(O, Or) and np.array_equal(A, Ar) and cost == costs[-1]
+        f = synth.make_frame(W, H, seed=6, K=2)
+        fs = opt.FrameSolver(gpu_state, W, H, batch=2)
+        fs.set_frame(0, f["mask_red"], f["constraints"]); fs.set_frame(1, np.zeros((H, W), np.uint8), f["constraints"])
+        fs.solve(2, 1, 2, 25)
+        r0 = fs.results(0, want_rgb=False)
+        fs.close()
+        Of, Af, _ = oracle.frame(f["mask_red"], f["constraints"], numIter=1, nIterations=2, lIterations=25, dtype=np.float32,
+                                 mode=1, trig=1)
+        assert np.array_equal(r0["offset"], Of) and np.array_equal(r0["angle"], Af)
+    finally:
+        gpu_state.set_tile(0, 0)
+        gpu_state.set_resident(True)
