@@ -278,6 +278,72 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_pcg_b for N % 4 == 0 (Gauss-Newton plans): the same element-wise update, four consecutive vertices per
+// lane so that every global access is 16 bytes wide (float4 of the Angle-shaped images, 2 x float4 of the
+// Offset-shaped ones) -- cdna guide G13: 16 B per lane is the coalescing sweet spot.  1-D grid over N/4 quads:
+// grid = (ceil(N/4/256), 1, frames), block = 256.  Excluded vertices are written back unchanged.
+__global__ __launch_bounds__(256) void k_pcg_b4(PlanDev pd, int l)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;          // quad index
+    const int nq = pd.N >> 2;
+    const size_t gb = (size_t)b * pd.N;
+    const float4* __restrict__ pO4 = (const float4*)(((l & 1) ? pd.pO0 : pd.pO1) + gb);
+    const float4* __restrict__ pA4 = (const float4*)(((l & 1) ? pd.pA0 : pd.pA1) + gb);
+    const double* rs = pd.red + (size_t)b * pd.nslots * NSHARD;
+    const float rho = read_scalar(rs + (size_t)(2 * l) * NSHARD);
+    const float sigma = read_scalar(rs + (size_t)(2 * l + 1) * NSHARD);
+    float alpha = 0.f;
+    if (sigma > 0.f) alpha = rho / sigma;
+    double d = 0.0;
+    const unsigned fw = q < nq ? ((const unsigned*)(pd.flags + gb))[q] : 0u;      // 4 flag bytes
+    if (fw & 0x20202020u) {
+        float4* dO4 = (float4*)(pd.deltaO + gb); float4* rO4 = (float4*)(pd.rO + gb); float4* zO4 = (float4*)(pd.zO + gb);
+        float4* dA4 = (float4*)(pd.deltaA + gb); float4* rA4 = (float4*)(pd.rA + gb); float4* zA4 = (float4*)(pd.zA + gb);
+        const float4* ApO4 = (const float4*)(pd.ApO + gb); const float4* mO4 = (const float4*)(pd.preO + gb);
+        const float4* ApA4 = (const float4*)(pd.ApA + gb); const float4* mA4 = (const float4*)(pd.preA + gb);
+        float po[8], apo[8], mo[8], dl[8], r[8], z[8], pa[4], apa[4], ma[4], dla[4], ra[4], za[4];
+        *(float4*)&po[0] = pO4[2 * q]; *(float4*)&po[4] = pO4[2 * q + 1];
+        *(float4*)&apo[0] = ApO4[2 * q]; *(float4*)&apo[4] = ApO4[2 * q + 1];
+        *(float4*)&mo[0] = mO4[2 * q]; *(float4*)&mo[4] = mO4[2 * q + 1];
+        *(float4*)&dl[0] = dO4[2 * q]; *(float4*)&dl[4] = dO4[2 * q + 1];
+        *(float4*)&r[0] = rO4[2 * q]; *(float4*)&r[4] = rO4[2 * q + 1];
+        *(float4*)&z[0] = zO4[2 * q]; *(float4*)&z[4] = zO4[2 * q + 1];
+        *(float4*)pa = pA4[q]; *(float4*)apa = ApA4[q]; *(float4*)ma = mA4[q];
+        *(float4*)dla = dA4[q]; *(float4*)ra = rA4[q]; *(float4*)za = zA4[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((fw >> (8 * k)) & F_ACT)) continue;
+            dl[2 * k] = dl[2 * k] + alpha * po[2 * k];
+            dl[2 * k + 1] = dl[2 * k + 1] + alpha * po[2 * k + 1];
+            dla[k] = dla[k] + alpha * pa[k];
+            r[2 * k] = r[2 * k] - alpha * apo[2 * k];
+            r[2 * k + 1] = r[2 * k + 1] - alpha * apo[2 * k + 1];
+            ra[k] = ra[k] - alpha * apa[k];
+            z[2 * k] = mo[2 * k] * r[2 * k];
+            z[2 * k + 1] = mo[2 * k + 1] * r[2 * k + 1];
+            za[k] = ma[k] * ra[k];
+            d += (double)dot3(z[2 * k], z[2 * k + 1], za[k], r[2 * k], r[2 * k + 1], ra[k]);
+        }
+        dO4[2 * q] = *(float4*)&dl[0]; dO4[2 * q + 1] = *(float4*)&dl[4];
+        rO4[2 * q] = *(float4*)&r[0]; rO4[2 * q + 1] = *(float4*)&r[4];
+        zO4[2 * q] = *(float4*)&z[0]; zO4[2 * q + 1] = *(float4*)&z[4];
+        dA4[q] = *(float4*)dla; rA4[q] = *(float4*)ra; zA4[q] = *(float4*)za;
+    }
+    // block reduction (4 wavefronts of a 1-D block)
+    __shared__ double wsum[4];
+    d = wave_sum(d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (t != 0.0)
+            __hip_atomic_fetch_add(pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD + (blockIdx.x % NSHARD), t,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PCGLinearUpdate: X += delta on non-excluded vertices
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd)
 {

@@ -83,7 +83,7 @@ struct Opt_State {
     KernelTimer ktimer;
     bool use_graph = true;
     bool use_resident = true;   // ArapFlow_SetResident
-    int tile = 0;               // ArapFlow_SetTile: phase-A variant of the two-kernel path (0 = direct loads)
+    int tile = -1;              // ArapFlow_SetTile: phase-A variant of the two-kernel path; -1 = choose per solve
 };
 
 struct Opt_Problem {
@@ -227,7 +227,7 @@ static void plan_enable_resident(Opt_Plan* p)
 static void plan_analyse_for_resident(Opt_Plan* p)
 {
     p->opt_res_ok = false;
-    if (!p->res_capable || p->res_frames || !p->st->use_resident) return;
+    if (p->res_frames) return;
     Opt_State* st = p->st;
     if (!p->d_notgrid) HC(hipMalloc(&p->d_notgrid, sizeof(int)));
     HC(hipMemsetAsync(p->d_notgrid, 0, sizeof(int), st->stream));
@@ -238,13 +238,12 @@ static void plan_analyse_for_resident(Opt_Plan* p)
     HC(hipMemcpyAsync(act.data(), p->pd.tileact, nt_all, hipMemcpyDeviceToHost, st->stream));
     HC(hipMemcpyAsync(&notgrid, p->d_notgrid, sizeof(int), hipMemcpyDeviceToHost, st->stream));
     HC(hipStreamSynchronize(st->stream));
-    if (notgrid) return;
     std::vector<int> tiles;
     for (int t = 0; t < nt_all; ++t)
         if (act[t]) tiles.push_back(t);
     const int nt = (int)tiles.size();
-    p->h_ntiles[0] = nt;
-    if (nt > RES_MAX_TILES) return;
+    p->h_ntiles[0] = nt;                        // also steers the automatic phase-A variant of the two-kernel path
+    if (notgrid || !p->res_capable || !st->use_resident || nt > RES_MAX_TILES) return;
     if (nt > 0)
         HC(hipMemcpyAsync((void*)p->rd.tilelist, tiles.data(), sizeof(int) * nt, hipMemcpyHostToDevice, st->stream));
     HC(hipMemcpyAsync((void*)p->rd.ntiles, &nt, sizeof(int), hipMemcpyHostToDevice, st->stream));
@@ -378,12 +377,24 @@ static void plan_upload_slots(Opt_Plan* p)
         }                                                                                   \
     } while (0)
 
+static bool plan_active_tiles_majority(const Opt_Plan* p)
+{
+    long act = 0;
+    for (int b = 0; b < p->nb; ++b) act += p->h_ntiles[b];
+    return 2 * act >= (long)p->nb * p->pd.tilesX * p->pd.tilesY;
+}
+
 // phase A of the two-kernel path: direct-load kernel or an LDS-staged tile shape (ArapFlow_SetTile)
 static const int kTileShapes[6][2] = {{0, 0}, {16, 16}, {32, 8}, {64, 4}, {32, 16}, {64, 8}};
 
 static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
 {
-    const int v = p->st->tile;
+    int v = p->st->tile;
+    if (v < 0) {
+        // default: LDS-staged 64x8 tiles when most tiles are active (profiles/r01_tile_sweep_two_kernel_path.txt:
+        // +14 % at full masks), direct loads for sparse masks (the staging of empty halo rows does not pay)
+        v = plan_active_tiles_majority(p) ? 5 : 0;
+    }
     if (v == 0) {
         LAUNCH(p, s, "PCGStepA", k_pcg_a, p->grid(), p->blk(), p->pd, l);
         return;
@@ -428,7 +439,10 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
     } else {
         for (int l = 0; l < L; ++l) {
             launch_pcg_a(p, s, l);
-            LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
+            if ((p->N & 3) == 0 && !p->pd.lm)      // 16-byte accesses need every frame's images 16-byte aligned
+                LAUNCH(p, s, "PCGStepB", k_pcg_b4, dim3((p->N / 4 + 255) / 256, p->nb, 1), dim3(256), p->pd, l);
+            else
+                LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
         }
     }
     LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, g, b, p->pd);
@@ -443,7 +457,7 @@ static void plan_gn_step(Opt_Plan* p)
         return;
     }
     // the captured resident launches bake in the group count, which follows the frames' active-tile counts
-    const int res_now = plan_resident_eligible(p) ? plan_resident_groups(p) : -(1 + p->st->tile);
+    const int res_now = plan_resident_eligible(p) ? plan_resident_groups(p) : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p));
     if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
@@ -840,6 +854,7 @@ void ArapFlow_SetResident(Opt_State* state, int on) { state->use_resident = on !
 
 int ArapFlow_SetTile(Opt_State* state, int tile_x, int tile_y)
 {
+    if (tile_x < 0 && tile_y < 0) { state->tile = -1; return 0; }         // automatic (default)
     for (int v = 0; v < 6; ++v)
         if (kTileShapes[v][0] == tile_x && kTileShapes[v][1] == tile_y) { state->tile = v; return 0; }
     return -1;

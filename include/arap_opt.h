@@ -184,9 +184,9 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg_iterations_per_frame,
  * operations; results are identical.  ArapFlow_SetResident(state, 0) forces the two-kernel path;
  * ArapFlow_SolverResidentLaunches counts resident launches since the solver was created. */
 void ArapFlow_SetResident(Opt_State* state, int on);
-/* Phase-A kernel of the two-kernel path: (0,0) = neighbours read through L1/L2 (default), or an LDS-staged tile of
- * (16,16), (32,8), (64,4), (32,16) or (64,8) vertices -- BASELINE config 5's tile sweep.  Same arithmetic, identical
- * results.  Returns -1 for any other shape. */
+/* Phase-A kernel of the two-kernel path: (0,0) = neighbours read through L1/L2, or an LDS-staged tile of (16,16),
+ * (32,8), (64,4), (32,16) or (64,8) vertices -- BASELINE config 5's tile sweep; (-1,-1) = automatic (default: 64x8
+ * when most tiles are active, direct otherwise).  Same arithmetic, identical results.  -1 for any other shape. */
 int ArapFlow_SetTile(Opt_State* state, int tile_x, int tile_y);
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s);
 /* The drop-in path (Opt_ProblemInit/Step/Solve) takes the resident kernel too when, at Init, the caller's

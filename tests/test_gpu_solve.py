@@ -344,7 +344,7 @@ def test_frame_edge_cases_empty_mask_and_no_constraints(gpu_state, oracle):
     assert np.array_equal(r[2]["offset"], O)
 
 
-@pytest.mark.parametrize("tile", [(16, 16), (32, 8), (64, 4), (32, 16), (64, 8)])
+@pytest.mark.parametrize("tile", [(0, 0), (16, 16), (32, 8), (64, 4), (32, 16), (64, 8), (-1, -1)])
 def test_lds_tiled_phase_a_is_bit_identical(gpu_state, oracle, tile):
     """two-kernel path with an LDS-staged phase A (BASELINE config 5's tile shapes): same bits as the oracle, for a
     generic UrShape (Opt_* path) and for a batch of frames whose size is not a multiple of the tile"""
@@ -368,5 +368,5 @@ def test_lds_tiled_phase_a_is_bit_identical(gpu_state, oracle, tile):
                                  mode=1, trig=1)
         assert np.array_equal(r0["offset"], Of) and np.array_equal(r0["angle"], Af)
     finally:
-        gpu_state.set_tile(0, 0)
+        gpu_state.set_tile(-1, -1)
         gpu_state.set_resident(True)

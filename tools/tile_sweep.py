@@ -28,4 +28,4 @@ for (W, H, B, K, full, name) in [(1920, 1080, 1, 1, True, "1920x1080 mask==0 x1"
         print("%-26s %-8s %10.2f %10.0f %10.2f %10.0f" % (name, "direct" if tile == (0, 0) else "%dx%d" % tile, ua,
                                                         64.0 * nact / ua / 1e3, ub, 96.0 * nact / ub / 1e3))
     fs.close()
-st.set_tile(0, 0)
+st.set_tile(-1, -1)
