@@ -229,7 +229,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     float rx[RES_SLOTS], ry[RES_SLOTS], ra[RES_SLOTS];
     float dx_[RES_SLOTS], dy_[RES_SLOTS], da_[RES_SLOTS];
     float apx[RES_SLOTS], apy[RES_SLOTS], apa[RES_SLOTS];
-    float ma_[RES_SLOTS];
+    float ma_[RES_SLOTS], mo_[RES_SLOTS];
     unsigned fl[RES_SLOTS];
 
     // LDS tile t: float2 P2[396] (px,py) | float2 CS[396] (cos,sin) | float PA[396]; cell = row*66 + col
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #pragma unroll
     for (int j = 0; j < RES_SLOTS; ++j) {
         const unsigned f = fl[j];
+        mo_[j] = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)];      // M^-1 of the Offset components
         if (wy == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lane + 1);
         if (wy == 3 && (f & F_E2)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 5 * LROW + lane + 1);
         if (lane == 0 && (f & F_E1)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (wy + 1) * LROW + 0);
@@ -298,6 +299,21 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     __syncthreads();
     const int nh = *nhalo;
+    // this lane's share of the halo list, decoded once: LDS cell (tile * LTILE + cell) and global vertex index
+    int hcell[RES_HALO_PER_THREAD], hgi[RES_HALO_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
+        const int c = tid + u * RES_THREADS;
+        hcell[u] = -1; hgi[u] = 0;
+        if (c < nh) {
+            const int id = hlist[c];
+            const int k = id / LPLANE, rem = id - k * LPLANE;
+            const int row = rem / LROW, col = rem - row * LROW;
+            const int2 tb = tbase[k];
+            hgi[u] = (tb.x + col - 1) + W * (tb.y + row - 1);
+            hcell[u] = k * LTILE + rem;              // float2 index of the P2 plane; PA plane = lds + k*LTILE + 4*LPLANE + rem
+        }
+    }
 
     bool alive = true;
     // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const float* T = lds + k * LTILE;
                 const float2 pv = TP2(T)[cell];
                 const float pa_ = TPA(T)[cell];
-                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = ma_[j];
+                const float mo = mo_[j], ma = ma_[j];
                 const int2 tb = tbase[k];
                 const int i = tb.x + lane + W * (tb.y + wy);
                 dx_[j] = dx_[j] + alpha * pv.x;
@@ -432,8 +448,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 ry[j] = ry[j] - alpha * apy[j];
                 ra[j] = ra[j] - alpha * apa[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-                st_pub_f2(pd.zO + gb + i, make_float2(zx, zy), fast);
-                st_pub_f(pd.zA + gb + i, za, fast);
+                st_pub_f2(pd.zO + gb + i, make_float2(zx, zy), fast);      // (publishing border vertices only was
+                st_pub_f(pd.zA + gb + i, za, fast);                         //  measured slower: divergent stores)
                 acc += (double)dot3(zx, zy, za, rx[j], ry[j], ra[j]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -452,22 +468,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         // (1) issue the sc1 loads of the neighbours' z for every halo cell of the workgroup (all in flight)
         float2 hz2[RES_HALO_PER_THREAD];
         float hz1[RES_HALO_PER_THREAD];
-        int hcell[RES_HALO_PER_THREAD];
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
-            const int c = tid + u * RES_THREADS;
-            hcell[u] = -1;
             hz2[u] = make_float2(0.f, 0.f);
             hz1[u] = 0.f;
-            if (c < nh) {
-                const int id = hlist[c];
-                const int k = id / LPLANE, rem = id - k * LPLANE;
-                const int row = rem / LROW, col = rem - row * LROW;
-                const int2 tb = tbase[k];
-                const int hi = (tb.x + col - 1) + W * (tb.y + row - 1);
-                hcell[u] = id;
-                hz2[u] = ld_sc1_f2(pd.zO + gb + hi);
-                hz1[u] = ld_sc1_f(pd.zA + gb + hi);
+            if (hcell[u] >= 0) {
+                hz2[u] = ld_sc1_f2(pd.zO + gb + hgi[u]);
+                hz1[u] = ld_sc1_f(pd.zA + gb + hgi[u]);
             }
         }
         // (2) own cells while those loads fly
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             const unsigned f = fl[j];
             if (f & F_ACT) {
                 float* T = lds + k * LTILE;
-                const float mo = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)], ma = ma_[j];
+                const float mo = mo_[j], ma = ma_[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
                 const float2 po = TP2(T)[cell];
                 TP2(T)[cell] = make_float2(zx + beta * po.x, zy + beta * po.y);
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
             if (hcell[u] >= 0) {
-                const int k = hcell[u] / LPLANE, rem = hcell[u] - k * LPLANE;
+                const int k = hcell[u] / LTILE, rem = hcell[u] - k * LTILE;
                 float* T = lds + k * LTILE;
                 const float2 po = TP2(T)[rem];
                 TP2(T)[rem] = make_float2(hz2[u].x + beta * po.x, hz2[u].y + beta * po.y);
