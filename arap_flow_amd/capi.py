@@ -66,6 +66,13 @@ def load():
             raise RuntimeError(
                 "libarapopt.so not built (%s): run `python -m arap_flow_amd.build` or "
                 "__graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: libarapopt.so links /opt/rocm's libamdhip64, torch (which owns the device
+        # buffers in the tests and the bench) bundles its own copy.  Whichever is loaded first serves both, but if
+        # this library came first and torch second, HIP reports no device to this library.  Load torch first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
