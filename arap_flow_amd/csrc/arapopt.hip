@@ -115,9 +115,6 @@ struct Opt_Plan {
     hipGraphExec_t gexec = nullptr;
     hipGraph_t graph = nullptr;
     int g_l = -1, g_nb = -1, g_res = -1;   // g_res: 0 = two-kernel path, else the resident group count
-    double prevCost[1] = {0.0};
-    bool cost_valid = false;
-    int cost_index = 0;
     // resident PCG (arap_resident.h): only for the frame solver (pixel-grid UrShape, host-known masks)
     bool res_capable = false;       // device has 256 CUs and the kernel fits one workgroup per CU
     bool res_frames = false;        // plan is driven by ArapFlow_Solver
@@ -474,8 +471,6 @@ static void plan_gn_step(Opt_Plan* p)
 static void plan_cost(Opt_Plan* p, int index)
 {
     LAUNCH(p, p->st->stream, "computeCost", k_cost, p->grid(), p->blk(), p->pd, index);
-    p->cost_index = index;
-    p->cost_valid = false;
 }
 
 // blocking read of the cost entry `index` of slot b (sum of its shards, rounded to float as the

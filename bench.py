@@ -213,6 +213,35 @@ def main():
             if os.path.exists(tf):
                 out["roofline"]["traffic"] = json.load(open(tf)).get(out["roofline"]["kernel"])
             out["resident_path"] = stats.get("resident_launches", 0) > 0
+            # measured device copy bandwidth next to the nominal peak: 1 GiB float32 copy, read + write
+            try:
+                src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()
+                dst = torch.empty_like(src)
+                dst.copy_(src); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    dst.copy_(src)
+                e1.record(); torch.cuda.synchronize()
+                out["roofline"]["measured_copy_GBs"] = 5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+                del src, dst
+            except Exception as e:
+                out["roofline"]["measured_copy_GBs"] = None
+            # warp stage alone: fused flow emission + rasteriser on the GPU vs the CPU rasteriser (oracle) on one frame
+            try:
+                torch.cuda.synchronize()
+                st.timer_begin()
+                for _ in range(5):
+                    fs.warp(S)
+                gpu_ms = st.timer_end() / 5 / S
+                r0 = fs.results(0)
+                from oracle import oracle as orc
+                t0w = time.time()
+                orc.warp_offset(solves[0]["rgb"], solves[0]["mask_red"], r0["offset"])
+                out["warp_stage"] = {"gpu_ms_per_frame": gpu_ms, "cpu_ms_per_frame": (time.time() - t0w) * 1e3,
+                                     "cpu": "oracle rasteriser, 1 thread (the reference's warp code is single threaded)"}
+            except Exception as e:
+                out["warp_stage"] = {"error": str(e)[:200]}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], a.schedule)
         print(json.dumps(out))
