@@ -304,6 +304,7 @@ static void plan_free(Opt_Plan* p)
     if (p->pd.red) (void)hipFree(p->pd.red);
     if (p->pd.costred) (void)hipFree(p->pd.costred);
     if (p->res_block) (void)hipFree(p->res_block);
+    if (p->rd.stamps) (void)hipFree(p->rd.stamps);
     if (p->d_notgrid) (void)hipFree(p->d_notgrid);
     if (p->lm_block) (void)hipFree(p->lm_block);
     if (p->pd.lmred) (void)hipFree(p->pd.lmred);

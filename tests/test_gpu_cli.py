@@ -147,3 +147,27 @@ def test_cpp_arap_deform_equals_python_twin_and_serves_para_gen(tmp_path, gpu_st
           "--multseg", "--arap_bin", b["arap_deform"]], str(tmp_path))
     lst = open(outp / "all_files.list").read().splitlines()
     assert len(lst) == 1 and np.abs(flo.flow_read(lst[0].split(" ")[2])).max() > 0.5
+
+
+def test_bench_contract_json_line(tmp_path):
+    """bench.py prints ONE JSON line with the contract's keys (tiny schedule and frames here)"""
+    import json
+    out = _run([osp.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--size", "214", "120",
+                "--schedule", "2", "2", "30"], str(tmp_path))
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "frames/s" and d["value"] > 0 and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1
