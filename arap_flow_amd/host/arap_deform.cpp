@@ -19,63 +19,63 @@ extern "C" {
 #include "flo_io.h"
 #include "png_io.h"
 
-struct inputPaths {                      // main.cpp:4-11
-    std::string inp_imgPath, inp_mskPath, inp_cstrPath, out_floPath, out_imgPath, out_mskPath;
+// one solve = one list-file line (ARAP/deformation/src/main.cpp:4-11,183-191)
+struct SolvePaths {
+    std::string rgb, mask, constraints, flow, warped_rgb, warped_mask;
 };
 
-static void usage()
-{
-#define p(msg) printf(msg "\n");
-    p("Usage:\n");
-    p("./arap_deform RGB Mask Constraint Flow warped_RGB warped_Mask\n");
-    p("Mask and warp image using the provided optical flow field.\n")
-    p("RGB \t\t [input]  path to an input RGB image (.png only)")
-    p("Mask\t\t [input]  path to an input mask image (.png only) where 0 for object, 1 for background")
-    p("Constraint \t [input]  path to list of constraints, text file")
-    p("Flow \t\t [output] path to optical flow image with (.flo only)")
-    p("warped_RGB \t [output] path to output warped image (.png), all intermediate directories must exist")
-    p("warped_Mask \t [output] path to output warped mask (.png), all intermediate directories must exist")
-#undef p
-}
+// the usage text of the reference's executable (main.cpp:13-24), verbatim: it is part of the CLI contract
+static const char kUsage[] =
+    "Usage:\n\n"
+    "./arap_deform RGB Mask Constraint Flow warped_RGB warped_Mask\n\n"
+    "Mask and warp image using the provided optical flow field.\n\n"
+    "RGB \t\t [input]  path to an input RGB image (.png only)\n"
+    "Mask\t\t [input]  path to an input mask image (.png only) where 0 for object, 1 for background\n"
+    "Constraint \t [input]  path to list of constraints, text file\n"
+    "Flow \t\t [output] path to optical flow image with (.flo only)\n"
+    "warped_RGB \t [output] path to output warped image (.png), all intermediate directories must exist\n"
+    "warped_Mask \t [output] path to output warped mask (.png), all intermediate directories must exist\n";
 
-// main.cpp:26-50
-static bool loadConstraints(std::vector<int32_t>& constraints, const std::string& path)
+// constraint file (main.cpp:26-50): a count n, then n rows of four integers x1 y1 x2 y2
+static bool read_constraint_file(const std::string& path, std::vector<int32_t>& rows)
 {
-    std::ifstream in(path, std::fstream::in);
-    if (!in.good()) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) {
         std::cout << "Could not open marker file " << path << std::endl;
         return false;
     }
-    unsigned int nMarkers = 0;
-    in >> nMarkers;
-    constraints.clear();
-    for (unsigned int m = 0; m < nMarkers; m++)
-        for (int i = 0; i < 4; ++i) {
-            int temp = 0;
-            in >> temp;
-            constraints.push_back(temp);
+    unsigned n = 0;
+    rows.clear();
+    if (fscanf(f, "%u", &n) == 1) {
+        rows.reserve(4 * (size_t)n);
+        for (size_t k = 0; k < 4 * (size_t)n; ++k) {
+            int v = 0;
+            if (fscanf(f, "%d", &v) != 1) v = 0;       // the reference's stream extraction leaves 0 on a short file
+            rows.push_back(v);
         }
+    }
+    fclose(f);
     return true;
 }
 
 struct Frame {
-    inputPaths paths;
+    SolvePaths paths;
     arapio::Image rgb;
     std::vector<uint8_t> mask_red;
     std::vector<int32_t> constraints;      // x1 y1 x2 y2 rows, file order then border pins
 };
 
-// loadData, main.cpp:116-138: constraints file, PNGs, then a pin-to-self constraint for every border pixel
-static bool loadData(const inputPaths& paths, Frame& f)
+// loadData of the reference (main.cpp:116-138): constraints file, PNGs, then a pin-to-self constraint for every border pixel
+static bool load_frame(const SolvePaths& paths, Frame& f)
 {
     f.paths = paths;
-    if (!loadConstraints(f.constraints, paths.inp_cstrPath)) return false;
+    if (!read_constraint_file(paths.constraints, f.constraints)) return false;
     std::string err;
-    if (!arapio::read_png_rgb(paths.inp_imgPath, f.rgb, err)) { printf("%s\n", err.c_str()); return false; }
+    if (!arapio::read_png_rgb(paths.rgb, f.rgb, err)) { printf("%s\n", err.c_str()); return false; }
     arapio::Image msk;
-    if (!arapio::read_png_rgb(paths.inp_mskPath, msk, err)) { printf("%s\n", err.c_str()); return false; }
+    if (!arapio::read_png_rgb(paths.mask, msk, err)) { printf("%s\n", err.c_str()); return false; }
     if (msk.w != f.rgb.w || msk.h != f.rgb.h) {
-        printf("Mask %s and image %s differ in size\n", paths.inp_mskPath.c_str(), paths.inp_imgPath.c_str());
+        printf("Mask %s and image %s differ in size\n", paths.mask.c_str(), paths.rgb.c_str());
         return false;
     }
     const int width = f.rgb.w, height = f.rgb.h;
@@ -92,24 +92,19 @@ static bool loadData(const inputPaths& paths, Frame& f)
 
 int main(int argc, const char* argv[])
 {
-    std::vector<inputPaths> lines;
-    inputPaths one;
-    if (argc == 7) {
-        one.inp_imgPath = argv[1]; one.inp_mskPath = argv[2]; one.inp_cstrPath = argv[3];
-        one.out_floPath = argv[4]; one.out_imgPath = argv[5]; one.out_mskPath = argv[6];
-        lines.push_back(one);
-    } else if (argc == 2) {
-        std::ifstream infile(argv[1]);
-        std::string line;
-        while (getline(infile, line)) {
-            std::stringstream s(line);
-            inputPaths q;
-            s >> q.inp_imgPath >> q.inp_mskPath >> q.inp_cstrPath >> q.out_floPath >> q.out_imgPath >> q.out_mskPath;
-            if (!q.out_mskPath.empty()) lines.push_back(q);
+    std::vector<SolvePaths> lines;
+    if (argc == 7) {                                                     // one frame on the command line
+        lines.push_back(SolvePaths{argv[1], argv[2], argv[3], argv[4], argv[5], argv[6]});
+    } else if (argc == 2) {                                              // list file
+        std::ifstream list(argv[1]);
+        for (std::string line; std::getline(list, line);) {
+            std::istringstream tok(line);
+            SolvePaths q;
+            if (tok >> q.rgb >> q.mask >> q.constraints >> q.flow >> q.warped_rgb >> q.warped_mask) lines.push_back(q);
         }
     } else {
         printf("Invalid Input!\n");
-        usage();
+        fputs(kUsage, stdout);
         return 1;
     }
     if (lines.empty()) {
@@ -140,12 +135,12 @@ int main(int argc, const char* argv[])
     size_t i = 0;
     while (i < lines.size()) {
         std::vector<Frame> batch(1);
-        if (!loadData(lines[i], batch[0])) return 1;
+        if (!load_frame(lines[i], batch[0])) return 1;
         const int w = batch[0].rgb.w, h = batch[0].rgb.h;
         size_t j = i + 1;
         while (j < lines.size() && batch.size() < maxBatch) {
             Frame f;
-            if (!loadData(lines[j], f)) return 1;
+            if (!load_frame(lines[j], f)) return 1;
             if (f.rgb.w != w || f.rgb.h != h) break;                     // next batch starts here (re-read then)
             batch.push_back(std::move(f));
             ++j;
@@ -172,9 +167,9 @@ int main(int argc, const char* argv[])
         for (size_t b = 0; b < batch.size(); ++b) {
             ArapFlow_SolverGetResults(solver, (unsigned)b, flow.data(), wrgb.data(), wmsk.data(), nullptr, nullptr, nullptr);
             std::string err;
-            if (!arapio::write_png_rgb(batch[b].paths.out_imgPath, w, h, wrgb.data(), err)) printf("%s\n", err.c_str());
-            if (!arapio::write_png_mask1(batch[b].paths.out_mskPath, w, h, wmsk.data(), err)) printf("%s\n", err.c_str());
-            arapio::write_flo(batch[b].paths.out_floPath, flow.data(), w, h);
+            if (!arapio::write_png_rgb(batch[b].paths.warped_rgb, w, h, wrgb.data(), err)) printf("%s\n", err.c_str());
+            if (!arapio::write_png_mask1(batch[b].paths.warped_mask, w, h, wmsk.data(), err)) printf("%s\n", err.c_str());
+            arapio::write_flo(batch[b].paths.flow, flow.data(), w, h);
             printf("Saved\n");
         }
         i = j;
