@@ -6,8 +6,9 @@
 // the reductions, which accumulate float32 per-vertex terms in float64 (DESIGN.md "Reductions").
 //
 // This translation unit is compiled with -ffp-contract=off: each operator below is one IEEE-754
-// operation, in the order written, so a CPU implementation with the same operation list reproduces
-// the results bit for bit (parity tier T3).
+// operation, in the order written, and fused multiply-adds appear only where fmaf()/fma() is written
+// (v_fma_f32 / v_pk_fma_f32: one rounding), so a CPU implementation with the same operation list
+// (oracle/, gcc -mfma -ffp-contract=off) reproduces the results bit for bit (parity tier T3).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -70,25 +71,25 @@ __device__ __forceinline__ float2 sincos_spec(float af)
     const double pio2_hi = 1.57079632673412561417e+00;
     const double pio2_lo = 6.07710050650619224932e-11;
     const double k = rint(a * two_over_pi);
-    const double r = (a - k * pio2_hi) - k * pio2_lo;
+    const double r = fma(-k, pio2_lo, fma(-k, pio2_hi, a));
     const double r2 = r * r;
     double ps = -1.0 / 1307674368000.0;
-    ps = ps * r2 + 1.0 / 6227020800.0;
-    ps = ps * r2 - 1.0 / 39916800.0;
-    ps = ps * r2 + 1.0 / 362880.0;
-    ps = ps * r2 - 1.0 / 5040.0;
-    ps = ps * r2 + 1.0 / 120.0;
-    ps = ps * r2 - 1.0 / 6.0;
-    const double sr = r + r * (r2 * ps);
+    ps = fma(ps, r2, 1.0 / 6227020800.0);
+    ps = fma(ps, r2, -1.0 / 39916800.0);
+    ps = fma(ps, r2, 1.0 / 362880.0);
+    ps = fma(ps, r2, -1.0 / 5040.0);
+    ps = fma(ps, r2, 1.0 / 120.0);
+    ps = fma(ps, r2, -1.0 / 6.0);
+    const double sr = fma(r, r2 * ps, r);
     double pc = 1.0 / 20922789888000.0;
-    pc = pc * r2 - 1.0 / 87178291200.0;
-    pc = pc * r2 + 1.0 / 479001600.0;
-    pc = pc * r2 - 1.0 / 3628800.0;
-    pc = pc * r2 + 1.0 / 40320.0;
-    pc = pc * r2 - 1.0 / 720.0;
-    pc = pc * r2 + 1.0 / 24.0;
-    pc = pc * r2 - 0.5;
-    const double cr = 1.0 + r2 * pc;
+    pc = fma(pc, r2, -1.0 / 87178291200.0);
+    pc = fma(pc, r2, 1.0 / 479001600.0);
+    pc = fma(pc, r2, -1.0 / 3628800.0);
+    pc = fma(pc, r2, 1.0 / 40320.0);
+    pc = fma(pc, r2, -1.0 / 720.0);
+    pc = fma(pc, r2, 1.0 / 24.0);
+    pc = fma(pc, r2, -0.5);
+    const double cr = fma(r2, pc, 1.0);
     const int q = (int)((long long)k & 3);
     double c, s;
     if (q == 0) { c = cr; s = sr; }
@@ -110,7 +111,7 @@ __device__ __forceinline__ float ginv(float d)
 
 __device__ __forceinline__ float dot3(float ax, float ay, float aa, float bx, float by, float ba)
 {
-    return (ax * bx + ay * by) + aa * ba;
+    return fmaf(aa, ba, fmaf(ay, by, ax * bx));
 }
 
 // neighbour index offset of stencil entry s

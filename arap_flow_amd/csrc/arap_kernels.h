@@ -108,23 +108,23 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
             const float2 On = sl.O[n], Un = sl.U[n];
             const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
             const float ox = Oi.x - On.x, oy = Oi.y - On.y;
-            const float ex = wr * (ox - (ci * dx - si * dy));
-            const float ey = wr * (oy - (si * dx + ci * dy));
-            const float fx = wr * ((cn * dx - sn * dy) - ox);
-            const float fy = wr * ((sn * dx + cn * dy) - oy);
-            const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
-            gx = gx + wr * (ex - fx);
-            gy = gy + wr * (ey - fy);
-            ga = ga - wr * (qx * ex + qy * ey);
+            const float ex = wr * (ox - fmaf(ci, dx, -(si * dy)));
+            const float ey = wr * (oy - fmaf(si, dx, ci * dy));
+            const float fx = wr * (fmaf(cn, dx, -(sn * dy)) - ox);
+            const float fy = wr * (fmaf(sn, dx, cn * dy) - oy);
+            const float qx = fmaf(-si, dx, -(ci * dy)), qy = fmaf(ci, dx, -(si * dy));
+            gx = fmaf(wr, ex - fx, gx);
+            gy = fmaf(wr, ey - fy, gy);
+            ga = fmaf(-wr, fmaf(qx, ex, qy * ey), ga);
             dO = dO + (wr * wr + wr * wr);
-            dA = dA + (wr * wr) * (qx * qx + qy * qy);
+            dA = fmaf(wr * wr, fmaf(qx, qx, qy * qy), dA);
         }
         float dOf = dO;
         if (f & F_FIT) {
             const float2 Ci = sl.C[v.i];
-            gx = gx + wf * (wf * (Oi.x - Ci.x));
-            gy = gy + wf * (wf * (Oi.y - Ci.y));
-            dOf = dO + wf * wf;
+            gx = fmaf(wf, wf * (Oi.x - Ci.x), gx);
+            gy = fmaf(wf, wf * (Oi.y - Ci.y), gy);
+            dOf = fmaf(wf, wf, dO);
         }
         const float rx = -gx, ry = -gy, ra = -ga;
         const float mo = ginv(dOf), ma = ginv(dA);
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
         if (l > 0) {
             const float2 zO = pd.zO[v.g];
             const float zA = pd.zA[v.g];
-            pO.x = zO.x + beta * pO.x;
-            pO.y = zO.y + beta * pO.y;
-            pA = zA + beta * pA;
+            pO.x = fmaf(beta, pO.x, zO.x);
+            pO.y = fmaf(beta, pO.y, zO.y);
+            pA = fmaf(beta, pA, zA);
         }
         poutO[v.g] = pO;
         poutA[v.g] = pA;
@@ -196,32 +196,32 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
             if (l > 0) {
                 const float2 zO = pd.zO[gb + n];
                 const float zA = pd.zA[gb + n];
-                qO.x = zO.x + beta * qO.x;
-                qO.y = zO.y + beta * qO.y;
-                qA = zA + beta * qA;
+                qO.x = fmaf(beta, qO.x, zO.x);
+                qO.y = fmaf(beta, qO.y, zO.y);
+                qA = fmaf(beta, qA, zA);
             }
             const float2 csn = pd.cs[gb + n];
             const float cn = csn.x, sn = csn.y;
             const float2 Un = sl.U[n];
             const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
-            const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
-            const float hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;
+            const float qx = fmaf(-si, dx, -(ci * dy)), qy = fmaf(ci, dx, -(si * dy));
+            const float hx = fmaf(-sn, dx, -(cn * dy)), hy = fmaf(cn, dx, -(sn * dy));
             const float px = pO.x - qO.x, py = pO.y - qO.y;
-            const float tx = px - qx * pA, ty = py - qy * pA;
-            ax = ax + wr2 * ((px + tx) - hx * qA);
-            ay = ay + wr2 * ((py + ty) - hy * qA);
-            aa = aa - wr2 * (qx * tx + qy * ty);
+            const float tx = fmaf(-qx, pA, px), ty = fmaf(-qy, pA, py);
+            ax = fmaf(wr2, fmaf(-hx, qA, px + tx), ax);
+            ay = fmaf(wr2, fmaf(-hy, qA, py + ty), ay);
+            aa = fmaf(-wr2, fmaf(qx, tx, qy * ty), aa);
         }
         if (f & F_FIT) {
             const float wf2 = sl.wf * sl.wf;
-            ax = ax + wf2 * pO.x;
-            ay = ay + wf2 * pO.y;
+            ax = fmaf(wf2, pO.x, ax);
+            ay = fmaf(wf2, pO.y, ay);
         }
         if (pd.lm) {                                   // applyJTJ + CtC*P (o.t:2076-2082)
             const float2 c = pd.CtCO[v.g];
-            ax = ax + c.x * pO.x;
-            ay = ay + c.y * pO.y;
-            aa = aa + pd.CtCA[v.g] * pA;
+            ax = fmaf(c.x, pO.x, ax);
+            ay = fmaf(c.y, pO.y, ay);
+            aa = fmaf(pd.CtCA[v.g], pA, aa);
         }
         pd.ApO[v.g] = make_float2(ax, ay);
         pd.ApA[v.g] = aa;
@@ -251,12 +251,12 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
         const float pA = pA_[v.g], ApA = pd.ApA[v.g], mA = pd.preA[v.g];
         float2 dO = pd.deltaO[v.g], rO = pd.rO[v.g];
         float dA = pd.deltaA[v.g], rA = pd.rA[v.g];
-        dO.x = dO.x + alpha * pO.x;
-        dO.y = dO.y + alpha * pO.y;
-        dA = dA + alpha * pA;
-        rO.x = rO.x - alpha * ApO.x;
-        rO.y = rO.y - alpha * ApO.y;
-        rA = rA - alpha * ApA;
+        dO.x = fmaf(alpha, pO.x, dO.x);
+        dO.y = fmaf(alpha, pO.y, dO.y);
+        dA = fmaf(alpha, pA, dA);
+        rO.x = fmaf(-alpha, ApO.x, rO.x);
+        rO.y = fmaf(-alpha, ApO.y, rO.y);
+        rA = fmaf(-alpha, ApA, rA);
         const float zx = mO.x * rO.x, zy = mO.y * rO.y, za = mA * rA;
         pd.deltaO[v.g] = dO;
         pd.deltaA[v.g] = dA;
@@ -314,12 +314,12 @@ __global__ __launch_bounds__(256) void k_pcg_b4(PlanDev pd, int l)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!((fw >> (8 * k)) & F_ACT)) continue;
-            dl[2 * k] = dl[2 * k] + alpha * po[2 * k];
-            dl[2 * k + 1] = dl[2 * k + 1] + alpha * po[2 * k + 1];
-            dla[k] = dla[k] + alpha * pa[k];
-            r[2 * k] = r[2 * k] - alpha * apo[2 * k];
-            r[2 * k + 1] = r[2 * k + 1] - alpha * apo[2 * k + 1];
-            ra[k] = ra[k] - alpha * apa[k];
+            dl[2 * k] = fmaf(alpha, po[2 * k], dl[2 * k]);
+            dl[2 * k + 1] = fmaf(alpha, po[2 * k + 1], dl[2 * k + 1]);
+            dla[k] = fmaf(alpha, pa[k], dla[k]);
+            r[2 * k] = fmaf(-alpha, apo[2 * k], r[2 * k]);
+            r[2 * k + 1] = fmaf(-alpha, apo[2 * k + 1], r[2 * k + 1]);
+            ra[k] = fmaf(-alpha, apa[k], ra[k]);
             z[2 * k] = mo[2 * k] * r[2 * k];
             z[2 * k + 1] = mo[2 * k + 1] * r[2 * k + 1];
             za[k] = ma[k] * ra[k];
@@ -382,16 +382,16 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_cost(PlanDev pd, int cost_in
             if (sl.M[n] != 0.0f) continue;
             const float2 On = sl.O[n], Un = sl.U[n];
             const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
-            const float ex = wr * ((Oi.x - On.x) - (cs.x * dx - cs.y * dy));
-            const float ey = wr * ((Oi.y - On.y) - (cs.y * dx + cs.x * dy));
-            t = t + ex * ex;
-            t = t + ey * ey;
+            const float ex = wr * ((Oi.x - On.x) - fmaf(cs.x, dx, -(cs.y * dy)));
+            const float ey = wr * ((Oi.y - On.y) - fmaf(cs.y, dx, cs.x * dy));
+            t = fmaf(ex, ex, t);
+            t = fmaf(ey, ey, t);
         }
         const float2 Ci = sl.C[v.i];
         if (Ci.x >= 0.0f && Ci.y >= 0.0f) {
             const float fx = wf * (Oi.x - Ci.x), fy = wf * (Oi.y - Ci.y);
-            t = t + fx * fx;
-            t = t + fy * fy;
+            t = fmaf(fx, fx, t);
+            t = fmaf(fy, fy, t);
         }
         d = (double)(0.5f * t);
     }
@@ -425,11 +425,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_export_jtf(PlanDev pd, float
             if (!(f & (1u << s))) continue;
             const float2 Un = sl.U[v.i + noff(s, pd.W)];
             const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
-            const float qx = -csi.y * dx - csi.x * dy, qy = csi.x * dx - csi.y * dy;
+            const float qx = fmaf(-csi.y, dx, -(csi.x * dy)), qy = fmaf(csi.x, dx, -(csi.y * dy));
             DO = DO + (wr * wr + wr * wr);
-            DA = DA + (wr * wr) * (qx * qx + qy * qy);
+            DA = fmaf(wr * wr, fmaf(qx, qx, qy * qy), DA);
         }
-        if (f & F_FIT) DO = DO + wf * wf;
+        if (f & F_FIT) DO = fmaf(wf, wf, DO);
         d_o = make_float2(DO, DO);
         d_a = DA;
     }

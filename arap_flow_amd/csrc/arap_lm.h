@@ -22,11 +22,11 @@ __device__ __forceinline__ void diag_raw(const PlanDev& pd, const Slot& sl, cons
         if (!(f & (1u << s))) continue;
         const float2 Un = sl.U[v.i + noff(s, pd.W)];
         const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
-        const float qx = -csi.y * dx - csi.x * dy, qy = csi.x * dx - csi.y * dy;
+        const float qx = fmaf(-csi.y, dx, -(csi.x * dy)), qy = fmaf(csi.x, dx, -(csi.y * dy));
         dO = dO + (wr * wr + wr * wr);
-        dA = dA + (wr * wr) * (qx * qx + qy * qy);
+        dA = fmaf(wr * wr, fmaf(qx, qx, qy * qy), dA);
     }
-    if (f & F_FIT) dO = dO + wf * wf;
+    if (f & F_FIT) dO = fmaf(wf, wf, dO);
     DO = dO; DA = dA;
 }
 
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_prepare(PlanDev pd, float
         const float cO = clampf(uO, min_diag * mO, max_diag * mO), cA = clampf(uA, min_diag * mA, max_diag * mA);
         pd.CtCO[v.g] = make_float2(cO, cO);
         pd.CtCA[v.g] = cA;
-        const float pO_ = 1.0f / (cO + radius * uO), pA_ = 1.0f / (cA + radius * uA);
+        const float pO_ = 1.0f / fmaf(radius, uO, cO), pA_ = 1.0f / fmaf(radius, uA, cA);
         pd.preO[v.g] = make_float2(pO_, pO_);
         pd.preA[v.g] = pA_;
         const float2 r = pd.rO[v.g];
@@ -101,22 +101,22 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_apply(PlanDev pd, const f
         const float cn = csn.x, sn = csn.y;
         const float2 Un = sl.U[n];
         const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
-        const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
-        const float hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;
+        const float qx = fmaf(-si, dx, -(ci * dy)), qy = fmaf(ci, dx, -(si * dy));
+        const float hx = fmaf(-sn, dx, -(cn * dy)), hy = fmaf(cn, dx, -(sn * dy));
         const float px = pO.x - qO.x, py = pO.y - qO.y;
-        const float tx = px - qx * pA, ty = py - qy * pA;
-        ax = ax + wr2 * ((px + tx) - hx * qA);
-        ay = ay + wr2 * ((py + ty) - hy * qA);
-        aa = aa - wr2 * (qx * tx + qy * ty);
+        const float tx = fmaf(-qx, pA, px), ty = fmaf(-qy, pA, py);
+        ax = fmaf(wr2, fmaf(-hx, qA, px + tx), ax);
+        ay = fmaf(wr2, fmaf(-hy, qA, py + ty), ay);
+        aa = fmaf(-wr2, fmaf(qx, tx, qy * ty), aa);
     }
     if (f & F_FIT) {
         const float wf2 = sl.wf * sl.wf;
-        ax = ax + wf2 * pO.x;
-        ay = ay + wf2 * pO.y;
+        ax = fmaf(wf2, pO.x, ax);
+        ay = fmaf(wf2, pO.y, ay);
     }
     const float2 c = pd.CtCO[v.g];
-    outO[v.g] = make_float2(ax + c.x * pO.x, ay + c.y * pO.y);
-    outA[v.g] = aa + pd.CtCA[v.g] * pA;
+    outO[v.g] = make_float2(fmaf(c.x, pO.x, ax), fmaf(c.y, pO.y, ay));
+    outA[v.g] = fmaf(pd.CtCA[v.g], pA, aa);
 }
 
 // PCGStep2_1stHalf: delta += alpha p   (p = the buffer k_pcg_a(l) wrote)
@@ -134,10 +134,10 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_step2a(PlanDev pd, int l)
     if (!v.in || !(pd.flags[v.g] & F_ACT)) return;
     float2 d = pd.deltaO[v.g];
     const float2 p = pO_[v.g];
-    d.x = d.x + alpha * p.x;
-    d.y = d.y + alpha * p.y;
+    d.x = fmaf(alpha, p.x, d.x);
+    d.y = fmaf(alpha, p.y, d.y);
     pd.deltaO[v.g] = d;
-    pd.deltaA[v.g] = pd.deltaA[v.g] + alpha * pA_[v.g];
+    pd.deltaA[v.g] = fmaf(alpha, pA_[v.g], pd.deltaA[v.g]);
 }
 
 // PCGStep2_2ndHalf: r = b - A delta ; z = pre r ; rho' ; q = 0.5 delta.(r + b)
@@ -184,19 +184,19 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_model_cost(PlanDev pd, in
             const int n = v.i + noff(s, pd.W);
             const float2 On = sl.O[n], Un = sl.U[n], dn = pd.deltaO[gb + n];
             const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
-            const float ex = wr * ((Oi.x - On.x) - (cs.x * dx - cs.y * dy));
-            const float ey = wr * ((Oi.y - On.y) - (cs.y * dx + cs.x * dy));
-            const float qx = -cs.y * dx - cs.x * dy, qy = cs.x * dx - cs.y * dy;
-            const float mx = ex + wr * ((di.x - dn.x) - qx * dai);
-            const float my = ey + wr * ((di.y - dn.y) - qy * dai);
-            t = t + mx * mx;
-            t = t + my * my;
+            const float ex = wr * ((Oi.x - On.x) - fmaf(cs.x, dx, -(cs.y * dy)));
+            const float ey = wr * ((Oi.y - On.y) - fmaf(cs.y, dx, cs.x * dy));
+            const float qx = fmaf(-cs.y, dx, -(cs.x * dy)), qy = fmaf(cs.x, dx, -(cs.y * dy));
+            const float mx = fmaf(wr, fmaf(-qx, dai, di.x - dn.x), ex);
+            const float my = fmaf(wr, fmaf(-qy, dai, di.y - dn.y), ey);
+            t = fmaf(mx, mx, t);
+            t = fmaf(my, my, t);
         }
         if (f & F_FIT) {
             const float2 Ci = sl.C[v.i];
-            const float mx = wf * (Oi.x - Ci.x) + wf * di.x, my = wf * (Oi.y - Ci.y) + wf * di.y;
-            t = t + mx * mx;
-            t = t + my * my;
+            const float mx = fmaf(wf, di.x, wf * (Oi.x - Ci.x)), my = fmaf(wf, di.y, wf * (Oi.y - Ci.y));
+            t = fmaf(mx, mx, t);
+            t = fmaf(my, my, t);
         }
         d = (double)(0.5f * t);
     }

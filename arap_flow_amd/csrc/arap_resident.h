@@ -87,6 +87,13 @@ __device__ __forceinline__ void st_pub_f(float* p, float v, bool fast)
 {
     if (fast) *p = v; else st_sc1_f(p, v);
 }
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+// (a.x*b.x + c.x, a.y*b.y + c.y) with one rounding each: v_pk_fma_f32
+__device__ __forceinline__ float2 fma2(float2 a, float2 b, float2 c)
+{
+    const v2f_t r = __builtin_elementwise_fma((v2f_t){a.x, a.y}, (v2f_t){b.x, b.y}, (v2f_t){c.x, c.y});
+    return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ float2 ld_sc1_f2(const float2* p)
 {
     const unsigned long long u =
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             const int deg = tid % 5, fit = tid / 5;
             float dO = 0.f;
             for (int k = 0; k < deg; ++k) dO = dO + (sl.wr * sl.wr + sl.wr * sl.wr);
-            if (fit) dO = dO + sl.wf * sl.wf;
+            if (fit) dO = fmaf(sl.wf, sl.wf, dO);
             moLUT[tid] = ginv(dO);
         }
         if (tid == 0) *nhalo = 0;
@@ -342,75 +349,45 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 // Branch free: every lane evaluates all four edges (LDS reads stay inside the halo'd tile) and
                 // keeps a contribution only where its flag bit is set, so the slots form one basic block and the
                 // scheduler can overlap one slot's LDS latency with another slot's arithmetic.  Selecting (not
-                // multiplying by 0) keeps NaNs of never-written halo cells out.
+                // multiplying by 0) keeps NaNs of never-written halo cells out.  (Edge weights wr2/0 instead of
+                // selects were tried: hoisted out of the loop they cost 45 VGPRs and spill, recomputed per
+                // iteration they cost as many instructions as the selects.)
                 const float* T = lds + k * LTILE;
                 const float2 pv = TP2(T)[cell];
                 const float2 csv = TCS(T)[cell];                 // (ci, si)
                 const float pa_ = TPA(T)[cell];
-                const float2 scv = make_float2(csv.y, csv.x);    // (si, ci)
-                const float2 a0 = make_float2(csv.y * pa_, -(csv.x * pa_));   // ( sp, -cp) = q pa for s=0
-                const float2 a2 = make_float2(csv.x * pa_, csv.y * pa_);      // ( cp,  sp) = q pa for s=2
+                const float ci = csv.x, si = csv.y;
+                const float2 pa2 = make_float2(pa_, pa_), w2 = make_float2(wr2, wr2);
                 float2 axy = make_float2(0.f, 0.f);
                 float aa = 0.f;
-                // On the pixel grid d = U(c)-U(n) = -s, so q = R'(A(c))d and h = R'(A(n))d are signed copies
-                // of (si,ci) / (sn,cn); products with -1/0/1, adding a zero, x-(-y) = x+y and
-                // (-a)+(-b) = -(a+b) are exact, so each block equals the generic k_pcg_a expression
-                //   t = dP - q pa ; a_xy += wr2((e+t) - h qA) ; aa -= wr2(qx tx + qy ty)
-                // value for value (only the sign of an exact zero may differ).
-                {   // s=(1,0): d=(-1,0)  q=( si,-ci)  h=( sn,-cn)
-                    const int nc = cell + 1;
-                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
-                    const float qA = TPA(T)[nc];
-                    const float2 e = pv - qO;
-                    const float2 t = e - a0;
-                    const float2 hq = make_float2(cn2.y * qA, -(cn2.x * qA));
-                    const float2 nax = axy + wr2 * ((e + t) - hq);
-                    const float2 m = scv * t;                    // (si tx, ci ty)
-                    const float naa = aa - wr2 * (m.x - m.y);
-                    const bool on = (f & F_E0) != 0;
-                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
+                // On the pixel grid d = U(c)-U(n) = -s, so q = R'(A(c))d and h = R'(A(n))d are signed copies of
+                // (si,ci) / (sn,cn) (a product with -1/0/1 and the addition of a zero are exact), and each
+                // block is the generic k_pcg_a expression
+                //   t = fma(-q, pa, dP) ; a_xy = fma(wr2, fma(-h, qA, dP + t), a_xy) ; aa = fma(-wr2, fma(qx,tx,qy ty), aa)
+                // on (x,y) pairs (v_pk_fma_f32), value for value (only the sign of an exact zero may differ).
+#define RES_EDGE(BIT, NC, NQX, NQY, NHX, NHY, QX, QY)                                                  \
+                {                                                                                      \
+                    const int nc = (NC);                                                               \
+                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];                                    \
+                    const float qA = TPA(T)[nc];                                                       \
+                    const float cn = cn2.x, sn = cn2.y;                                                \
+                    const float2 e = pv - qO;                                                          \
+                    const float2 t = fma2(make_float2(NQX, NQY), pa2, e);                              \
+                    const float2 u = fma2(make_float2(NHX, NHY), make_float2(qA, qA), e + t);          \
+                    const float2 nax = fma2(w2, u, axy);                                               \
+                    const float naa = fmaf(-wr2, fmaf(QX, t.x, (QY) * t.y), aa);                       \
+                    const bool on = (f & (BIT)) != 0;                                                  \
+                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;        \
+                    (void)cn; (void)sn;                                                                \
                 }
-                {   // s=(-1,0): d=(1,0)  q=(-si, ci)  h=(-sn, cn)
-                    const int nc = cell - 1;
-                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
-                    const float qA = TPA(T)[nc];
-                    const float2 e = pv - qO;
-                    const float2 t = e + a0;
-                    const float2 hq = make_float2(cn2.y * qA, -(cn2.x * qA));
-                    const float2 nax = axy + wr2 * ((e + t) + hq);
-                    const float2 m = scv * t;
-                    const float naa = aa - wr2 * (m.y - m.x);
-                    const bool on = (f & F_E1) != 0;
-                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
-                }
-                {   // s=(0,1): d=(0,-1)  q=( ci, si)  h=( cn, sn)
-                    const int nc = cell + LROW;
-                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
-                    const float qA = TPA(T)[nc];
-                    const float2 e = pv - qO;
-                    const float2 t = e - a2;
-                    const float2 hq = cn2 * qA;
-                    const float2 nax = axy + wr2 * ((e + t) - hq);
-                    const float2 m = csv * t;                    // (ci tx, si ty)
-                    const float naa = aa - wr2 * (m.x + m.y);
-                    const bool on = (f & F_E2) != 0;
-                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
-                }
-                {   // s=(0,-1): d=(0,1)  q=(-ci,-si)  h=(-cn,-sn)
-                    const int nc = cell - LROW;
-                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];
-                    const float qA = TPA(T)[nc];
-                    const float2 e = pv - qO;
-                    const float2 t = e + a2;
-                    const float2 hq = cn2 * qA;
-                    const float2 nax = axy + wr2 * ((e + t) + hq);
-                    const float2 m = csv * t;
-                    const float naa = aa + wr2 * (m.x + m.y);
-                    const bool on = (f & F_E3) != 0;
-                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;
-                }
+                //        bit   neighbour     -q          -h          q
+                RES_EDGE(F_E0, cell + 1,     -si,  ci,   -sn,  cn,    si, -ci)      // s=( 1, 0): q=( si,-ci) h=( sn,-cn)
+                RES_EDGE(F_E1, cell - 1,      si, -ci,    sn, -cn,   -si,  ci)      // s=(-1, 0): q=(-si, ci) h=(-sn, cn)
+                RES_EDGE(F_E2, cell + LROW,  -ci, -si,   -cn, -sn,    ci,  si)      // s=( 0, 1): q=( ci, si) h=( cn, sn)
+                RES_EDGE(F_E3, cell - LROW,   ci,  si,    cn,  sn,   -ci, -si)      // s=( 0,-1): q=(-ci,-si) h=(-cn,-sn)
+#undef RES_EDGE
                 {
-                    const float2 nax = axy + wf2 * pv;
+                    const float2 nax = fma2(make_float2(wf2, wf2), pv, axy);
                     const bool on = (f & F_FIT) != 0;
                     axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y;
                 }
@@ -441,12 +418,12 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const float mo = mo_[j], ma = ma_[j];
                 const int2 tb = tbase[k];
                 const int i = tb.x + lane + W * (tb.y + wy);
-                dx_[j] = dx_[j] + alpha * pv.x;
-                dy_[j] = dy_[j] + alpha * pv.y;
-                da_[j] = da_[j] + alpha * pa_;
-                rx[j] = rx[j] - alpha * apx[j];
-                ry[j] = ry[j] - alpha * apy[j];
-                ra[j] = ra[j] - alpha * apa[j];
+                dx_[j] = fmaf(alpha, pv.x, dx_[j]);
+                dy_[j] = fmaf(alpha, pv.y, dy_[j]);
+                da_[j] = fmaf(alpha, pa_, da_[j]);
+                rx[j] = fmaf(-alpha, apx[j], rx[j]);
+                ry[j] = fmaf(-alpha, apy[j], ry[j]);
+                ra[j] = fmaf(-alpha, apa[j], ra[j]);
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
                 st_pub_f2(pd.zO + gb + i, make_float2(zx, zy), fast);      // (publishing border vertices only was
                 st_pub_f(pd.zA + gb + i, za, fast);                         //  measured slower: divergent stores)
@@ -487,8 +464,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const float mo = mo_[j], ma = ma_[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
                 const float2 po = TP2(T)[cell];
-                TP2(T)[cell] = make_float2(zx + beta * po.x, zy + beta * po.y);
-                TPA(T)[cell] = za + beta * TPA(T)[cell];
+                TP2(T)[cell] = make_float2(fmaf(beta, po.x, zx), fmaf(beta, po.y, zy));
+                TPA(T)[cell] = fmaf(beta, TPA(T)[cell], za);
             }
         }
         // (3) halo cells: p_halo = z_halo + beta p_halo (the owner computes the same expression)
@@ -498,8 +475,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const int k = hcell[u] / LTILE, rem = hcell[u] - k * LTILE;
                 float* T = lds + k * LTILE;
                 const float2 po = TP2(T)[rem];
-                TP2(T)[rem] = make_float2(hz2[u].x + beta * po.x, hz2[u].y + beta * po.y);
-                TPA(T)[rem] = hz1[u] + beta * TPA(T)[rem];
+                TP2(T)[rem] = make_float2(fmaf(beta, po.x, hz2[u].x), fmaf(beta, po.y, hz2[u].y));
+                TPA(T)[rem] = fmaf(beta, TPA(T)[rem], hz1[u]);
             }
         }
         __syncthreads();

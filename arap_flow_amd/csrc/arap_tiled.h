@@ -47,9 +47,9 @@ __global__ __launch_bounds__(TX* TY) void k_pcg_a_lds(PlanDev pd, int l)
         if (l > 0) {
             const float2 zO = pd.zO[gb + j];
             const float zA = pd.zA[gb + j];
-            pO.x = zO.x + beta * pO.x;
-            pO.y = zO.y + beta * pO.y;
-            pA = zA + beta * pA;
+            pO.x = fmaf(beta, pO.x, zO.x);
+            pO.y = fmaf(beta, pO.y, zO.y);
+            pA = fmaf(beta, pA, zA);
         }
         sP[cell] = pO;
         sA[cell] = pA;
@@ -86,24 +86,24 @@ __global__ __launch_bounds__(TX* TY) void k_pcg_a_lds(PlanDev pd, int l)
             const float cn = csn.x, sn = csn.y;
             const float2 Un = sl.U[i + noff(s, W)];
             const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
-            const float qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
-            const float hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;
+            const float qx = fmaf(-si, dx, -(ci * dy)), qy = fmaf(ci, dx, -(si * dy));
+            const float hx = fmaf(-sn, dx, -(cn * dy)), hy = fmaf(cn, dx, -(sn * dy));
             const float px = pO.x - qO.x, py = pO.y - qO.y;
-            const float tx_ = px - qx * pA, ty_ = py - qy * pA;
-            ax = ax + wr2 * ((px + tx_) - hx * qA);
-            ay = ay + wr2 * ((py + ty_) - hy * qA);
-            aa = aa - wr2 * (qx * tx_ + qy * ty_);
+            const float tx_ = fmaf(-qx, pA, px), ty_ = fmaf(-qy, pA, py);
+            ax = fmaf(wr2, fmaf(-hx, qA, px + tx_), ax);
+            ay = fmaf(wr2, fmaf(-hy, qA, py + ty_), ay);
+            aa = fmaf(-wr2, fmaf(qx, tx_, qy * ty_), aa);
         }
         if (f & F_FIT) {
             const float wf2 = sl.wf * sl.wf;
-            ax = ax + wf2 * pO.x;
-            ay = ay + wf2 * pO.y;
+            ax = fmaf(wf2, pO.x, ax);
+            ay = fmaf(wf2, pO.y, ay);
         }
         if (pd.lm) {
             const float2 c = pd.CtCO[gb + i];
-            ax = ax + c.x * pO.x;
-            ay = ay + c.y * pO.y;
-            aa = aa + pd.CtCA[gb + i] * pA;
+            ax = fmaf(c.x, pO.x, ax);
+            ay = fmaf(c.y, pO.y, ay);
+            aa = fmaf(pd.CtCA[gb + i], pA, aa);
         }
         pd.ApO[gb + i] = make_float2(ax, ay);
         pd.ApA[gb + i] = aa;

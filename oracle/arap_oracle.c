@@ -12,14 +12,15 @@
  *   - full 19/8/400 schedule vs the reference golden ARAP/warping/cat512_iFlo.flo (tier T4)
  *   - oracle_warp vs the reference golden cat512_wRGB.png / cat512_wMsk.png and vs the reference's
  *     own warp_image compiled from its sources into oracle/_ref/ (bit exact)
- * Compiled with -ffp-contract=off: every float operation below is a single IEEE-754 operation.
+ * Compiled with -ffp-contract=off: every operator below is a single IEEE-754 operation; fused multiply-adds are
+ * written explicitly (fmaf/fma, compiled to hardware FMA with -mfma) at exactly the sites where the HIP kernels fuse.
  */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 /* ---------------------------------------------------------------------------------------------
- * arap_sincos_spec: cos/sin of a float-valued angle from IEEE double +,-,*,rint only, in a fixed
+ * arap_sincos_spec: cos/sin of a float-valued angle from IEEE double +,-,*,fma,rint only, in a fixed
  * operation order, so that a second implementation with the same operation list (the HIP kernel,
  * arap_flow_amd/csrc/arap_device.h) returns the same bits.  The reference calls CUDA libdevice
  * __nv_cosf/__nv_sinf (ARAP/API/src/util.t:160-174), accurate to ~1-2 ulp; this routine is
@@ -32,26 +33,26 @@ void arap_sincos_spec(double a, double *c, double *s)
     const double pio2_hi = 1.57079632673412561417e+00; /* 33 bits of pi/2 */
     const double pio2_lo = 6.07710050650619224932e-11; /* pi/2 - pio2_hi */
     double k = rint(a * two_over_pi);
-    double r = (a - k * pio2_hi) - k * pio2_lo;
+    double r = fma(-k, pio2_lo, fma(-k, pio2_hi, a));
     double r2 = r * r;
-    /* sin r = r (1 + r2 (S1 + r2 (S2 + ...))) ; cos r = 1 + r2 (C1 + r2 (C2 + ...)) */
+    /* sin r = r (1 + r2 (S1 + r2 (S2 + ...))) ; cos r = 1 + r2 (C1 + r2 (C2 + ...)), Horner with fused steps */
     double ps = -1.0 / 1307674368000.0;            /* -1/15! */
-    ps = ps * r2 + 1.0 / 6227020800.0;             /*  1/13! */
-    ps = ps * r2 - 1.0 / 39916800.0;               /* -1/11! */
-    ps = ps * r2 + 1.0 / 362880.0;                 /*  1/9!  */
-    ps = ps * r2 - 1.0 / 5040.0;                   /* -1/7!  */
-    ps = ps * r2 + 1.0 / 120.0;                    /*  1/5!  */
-    ps = ps * r2 - 1.0 / 6.0;                      /* -1/3!  */
-    double sr = r + r * (r2 * ps);
+    ps = fma(ps, r2, 1.0 / 6227020800.0);          /*  1/13! */
+    ps = fma(ps, r2, -1.0 / 39916800.0);           /* -1/11! */
+    ps = fma(ps, r2, 1.0 / 362880.0);              /*  1/9!  */
+    ps = fma(ps, r2, -1.0 / 5040.0);               /* -1/7!  */
+    ps = fma(ps, r2, 1.0 / 120.0);                 /*  1/5!  */
+    ps = fma(ps, r2, -1.0 / 6.0);                  /* -1/3!  */
+    double sr = fma(r, r2 * ps, r);
     double pc = 1.0 / 20922789888000.0;            /*  1/16! */
-    pc = pc * r2 - 1.0 / 87178291200.0;            /* -1/14! */
-    pc = pc * r2 + 1.0 / 479001600.0;              /*  1/12! */
-    pc = pc * r2 - 1.0 / 3628800.0;                /* -1/10! */
-    pc = pc * r2 + 1.0 / 40320.0;                  /*  1/8!  */
-    pc = pc * r2 - 1.0 / 720.0;                    /* -1/6!  */
-    pc = pc * r2 + 1.0 / 24.0;                     /*  1/4!  */
-    pc = pc * r2 - 0.5;                            /* -1/2!  */
-    double cr = 1.0 + r2 * pc;
+    pc = fma(pc, r2, -1.0 / 87178291200.0);        /* -1/14! */
+    pc = fma(pc, r2, 1.0 / 479001600.0);           /*  1/12! */
+    pc = fma(pc, r2, -1.0 / 3628800.0);            /* -1/10! */
+    pc = fma(pc, r2, 1.0 / 40320.0);               /*  1/8!  */
+    pc = fma(pc, r2, -1.0 / 720.0);                /* -1/6!  */
+    pc = fma(pc, r2, 1.0 / 24.0);                  /*  1/4!  */
+    pc = fma(pc, r2, -0.5);                        /* -1/2!  */
+    double cr = fma(r2, pc, 1.0);
     long long q = (long long)k;
     switch ((int)(q & 3)) {
     case 0: *c = cr; *s = sr; break;

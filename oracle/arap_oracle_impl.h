@@ -13,6 +13,9 @@
  * oracle_residuals_*) and pins the whole schedule against the reference's golden vector
  * ARAP/warping/cat512_iFlo.flo.
  *
+ * Arithmetic: one IEEE operation per operator (-ffp-contract=off) plus explicit FMA() at the sites DESIGN.md lists;
+ * the HIP kernels use the same sites, which is what makes the float32 variant their bit-level twin (tier T3).
+ *
  * Layout (o.t:376-387): row major, x fastest, index = x + W*y, channels interleaved.
  *   O, U, C : REAL[N][2]      A, M : REAL[N]      3-vectors (delta, r, p, ...) : REAL[N][3] = (Ox,Oy,A)
  */
@@ -24,6 +27,8 @@
 #define CAT_(a, b) a##b
 #define CAT(a, b) CAT_(a, b)
 #define FN(name) CAT(name, SUF)
+/* fused multiply-add a*b + c with ONE rounding, at exactly the sites the HIP kernels fuse */
+#define FMA(a, b, c) (sizeof(REAL) == 4 ? (REAL)fmaf((float)(a), (float)(b), (float)(c)) : (REAL)fma((double)(a), (double)(b), (double)(c)))
 
 /* reduction mode for the three PCG dot products and the cost:
  *   0 : accumulate in REAL, sequentially in index order (one fixed instance of the order the
@@ -101,7 +106,7 @@ static void FN(residuals_at)(const FN(Prob) * pb, const REAL *O, const REAL *A, 
     for (int k = 0; k < 4; ++k) {
         if (!FN(edge)(pb, x, y, k, &n)) continue;
         REAL dx = pb->U[2 * i] - pb->U[2 * n], dy = pb->U[2 * i + 1] - pb->U[2 * n + 1];
-        REAL rx = c * dx - s * dy, ry = s * dx + c * dy;
+        REAL rx = FMA(c, dx, -(s * dy)), ry = FMA(s, dx, c * dy);
         out[2 * k] = pb->wr * ((O[2 * i] - O[2 * n]) - rx);
         out[2 * k + 1] = pb->wr * ((O[2 * i + 1] - O[2 * n + 1]) - ry);
     }
@@ -135,7 +140,7 @@ static double FN(cost_)(const FN(Prob) * pb, const REAL *O, const REAL *A, int m
             REAL e[10];
             FN(residuals_at)(pb, O, A, x, y, e);
             REAL t = (REAL)0;
-            for (int k = 0; k < 10; ++k) t = t + e[k] * e[k];
+            for (int k = 0; k < 10; ++k) t = FMA(e[k], e[k], t);
             t = (REAL)0.5 * t;
             if (mode == 1) accd += (double)t; else accr = accr + t;
         }
@@ -173,24 +178,24 @@ static void FN(evalJTF_at)(const FN(Prob) * pb, const REAL *O, const REAL *A, in
         REAL dx = pb->U[2 * i] - pb->U[2 * n], dy = pb->U[2 * i + 1] - pb->U[2 * n + 1];
         REAL ox = O[2 * i] - O[2 * n], oy = O[2 * i + 1] - O[2 * n + 1];
         /* e_s(c) */
-        REAL ex = wr * (ox - (ci * dx - si * dy));
-        REAL ey = wr * (oy - (si * dx + ci * dy));
+        REAL ex = wr * (ox - FMA(ci, dx, -(si * dy)));
+        REAL ey = wr * (oy - FMA(si, dx, ci * dy));
         /* e_{-s}(n) = w_r[-(O(c)-O(n)) + R(A(n)) d_s(c)] */
-        REAL fx = wr * ((cn * dx - sn * dy) - ox);
-        REAL fy = wr * ((sn * dx + cn * dy) - oy);
+        REAL fx = wr * (FMA(cn, dx, -(sn * dy)) - ox);
+        REAL fy = wr * (FMA(sn, dx, cn * dy) - oy);
         /* q_s(c) = R'(A(c)) d_s(c) */
-        REAL qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
-        gx = gx + wr * (ex - fx);
-        gy = gy + wr * (ey - fy);
-        ga = ga - wr * (qx * ex + qy * ey);
+        REAL qx = FMA(-si, dx, -(ci * dy)), qy = FMA(ci, dx, -(si * dy));
+        gx = FMA(wr, ex - fx, gx);
+        gy = FMA(wr, ey - fy, gy);
+        ga = FMA(-wr, FMA(qx, ex, qy * ey), ga);
         dO = dO + (wr * wr + wr * wr);
-        dA = dA + (wr * wr) * (qx * qx + qy * qy);
+        dA = FMA(wr * wr, FMA(qx, qx, qy * qy), dA);
     }
     REAL dOf = dO;
     if (FN(fit)(pb, i)) {
-        gx = gx + wf * (wf * (O[2 * i] - pb->C[2 * i]));
-        gy = gy + wf * (wf * (O[2 * i + 1] - pb->C[2 * i + 1]));
-        dOf = dO + wf * wf;
+        gx = FMA(wf, wf * (O[2 * i] - pb->C[2 * i]), gx);
+        gy = FMA(wf, wf * (O[2 * i + 1] - pb->C[2 * i + 1]), gy);
+        dOf = FMA(wf, wf, dO);
     }
     g[0] = gx; g[1] = gy; g[2] = ga;
     d[0] = dOf; d[1] = dOf; d[2] = dA;
@@ -223,19 +228,19 @@ static void FN(applyJTJ_at)(const FN(Prob) * pb, const REAL *cs, const REAL *P, 
         if (!FN(edge)(pb, x, y, k, &n)) continue;
         REAL cn = cs[2 * n], sn = cs[2 * n + 1];
         REAL dx = pb->U[2 * i] - pb->U[2 * n], dy = pb->U[2 * i + 1] - pb->U[2 * n + 1];
-        REAL qx = -si * dx - ci * dy, qy = ci * dx - si * dy;   /* R'(A(c)) d */
-        REAL hx = -sn * dx - cn * dy, hy = cn * dx - sn * dy;   /* R'(A(n)) d */
+        REAL qx = FMA(-si, dx, -(ci * dy)), qy = FMA(ci, dx, -(si * dy));   /* R'(A(c)) d */
+        REAL hx = FMA(-sn, dx, -(cn * dy)), hy = FMA(cn, dx, -(sn * dy));   /* R'(A(n)) d */
         REAL px = P[3 * i] - P[3 * n], py = P[3 * i + 1] - P[3 * n + 1];
         REAL pa = P[3 * i + 2], pn = P[3 * n + 2];
-        REAL tx = px - qx * pa, ty = py - qy * pa;              /* dP - q P_A(c) */
-        ax = ax + wr2 * ((px + tx) - hx * pn);
-        ay = ay + wr2 * ((py + ty) - hy * pn);
-        aa = aa - wr2 * (qx * tx + qy * ty);
+        REAL tx = FMA(-qx, pa, px), ty = FMA(-qy, pa, py);      /* dP - q P_A(c) */
+        ax = FMA(wr2, FMA(-hx, pn, px + tx), ax);
+        ay = FMA(wr2, FMA(-hy, pn, py + ty), ay);
+        aa = FMA(-wr2, FMA(qx, tx, qy * ty), aa);
     }
     if (FN(fit)(pb, i)) {
         REAL wf2 = pb->wf * pb->wf;
-        ax = ax + wf2 * P[3 * i];
-        ay = ay + wf2 * P[3 * i + 1];
+        ax = FMA(wf2, P[3 * i], ax);
+        ay = FMA(wf2, P[3 * i + 1], ay);
     }
     out[0] = ax; out[1] = ay; out[2] = aa;
 }
@@ -271,7 +276,7 @@ static inline REAL FN(ginv)(REAL d)
 
 static inline REAL FN(dot3)(const REAL *a, const REAL *b)
 {
-    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+    return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0]));
 }
 
 /* solver state that the reference keeps in its plan (makePlan, solverGPUGaussNewton.t:1254-1284);
@@ -371,8 +376,8 @@ static double FN(solve_)(const FN(Prob) * pb, FN(Plan) * pl, REAL *O, REAL *A, i
                     REAL *dl = pl->delta + 3 * i, *r = pl->r + 3 * i, *z = pl->z + 3 * i;
                     const REAL *p = pl->p + 3 * i, *Ap = pl->Ap + 3 * i, *pre = pl->pre + 3 * i;
                     for (int k = 0; k < 3; ++k) {
-                        dl[k] = dl[k] + alpha * p[k];
-                        r[k] = r[k] - alpha * Ap[k];
+                        dl[k] = FMA(alpha, p[k], dl[k]);
+                        r[k] = FMA(-alpha, Ap[k], r[k]);
                         z[k] = pre[k] * r[k];
                     }
                     REAL t = FN(dot3)(z, r);
@@ -389,7 +394,7 @@ static double FN(solve_)(const FN(Prob) * pb, FN(Plan) * pl, REAL *O, REAL *A, i
                 for (int x = 0; x < W; ++x) {
                     size_t i = (size_t)(x + W * y);
                     if (!FN(act)(pb, (int)i)) continue;
-                    for (int k = 0; k < 3; ++k) pl->p[3 * i + k] = pl->z[3 * i + k] + beta * pl->p[3 * i + k];
+                    for (int k = 0; k < 3; ++k) pl->p[3 * i + k] = FMA(beta, pl->p[3 * i + k], pl->z[3 * i + k]);
                 }
             rho = rhoNew;                                /* D2D copy alphaNum <- betaNum (:1091) */
         }
@@ -439,7 +444,7 @@ static void FN(apply_lm_at)(const FN(Prob) * pb, const REAL *cs, const REAL *CtC
 {
     size_t i = (size_t)(x + pb->W * y);
     FN(applyJTJ_at)(pb, cs, P, x, y, out);
-    for (int k = 0; k < 3; ++k) out[k] = out[k] + CtC[3 * i + k] * P[3 * i + k];
+    for (int k = 0; k < 3; ++k) out[k] = FMA(CtC[3 * i + k], P[3 * i + k], out[k]);
 }
 
 int FN(oracle_solve_lm)(int W, int H, REAL *O, REAL *A, const REAL *U, const REAL *C, const REAL *M, REAL wf,
@@ -480,7 +485,7 @@ int FN(oracle_solve_lm)(int W, int H, REAL *O, REAL *A, const REAL *U, const REA
                     const REAL mult = ((REAL)1 / SSq[3 * i + k]) / radius;     /* PCGFinalizeDiagonal */
                     const REAL ctc = FN(clampr)(unclamped, min_diag * mult, max_diag * mult);
                     CtC[3 * i + k] = ctc;
-                    pl->pre[3 * i + k] = (REAL)1 / (ctc + radius * unclamped);
+                    pl->pre[3 * i + k] = (REAL)1 / FMA(radius, unclamped, ctc);
                     b[3 * i + k] = pl->r[3 * i + k];
                     pl->p[3 * i + k] = pl->pre[3 * i + k] * pl->r[3 * i + k];
                 }
@@ -505,7 +510,7 @@ int FN(oracle_solve_lm)(int W, int H, REAL *O, REAL *A, const REAL *U, const REA
             if (((l + 1) % residual_reset_period) == 0) {
                 for (size_t i = 0; i < N; ++i) {                               /* PCGStep2_1stHalf */
                     if (!FN(act)(pb, (int)i)) continue;
-                    for (int k = 0; k < 3; ++k) pl->delta[3 * i + k] = pl->delta[3 * i + k] + alpha * pl->p[3 * i + k];
+                    for (int k = 0; k < 3; ++k) pl->delta[3 * i + k] = FMA(alpha, pl->p[3 * i + k], pl->delta[3 * i + k]);
                 }
                 for (int y = 0; y < H; ++y)                                    /* computeAdelta */
                     for (int x = 0; x < W; ++x) {
@@ -528,8 +533,8 @@ int FN(oracle_solve_lm)(int W, int H, REAL *O, REAL *A, const REAL *U, const REA
                     if (!FN(act)(pb, (int)i)) continue;
                     REAL rb[3];
                     for (int k = 0; k < 3; ++k) {
-                        pl->delta[3 * i + k] = pl->delta[3 * i + k] + alpha * pl->p[3 * i + k];
-                        pl->r[3 * i + k] = pl->r[3 * i + k] - alpha * pl->Ap[3 * i + k];
+                        pl->delta[3 * i + k] = FMA(alpha, pl->p[3 * i + k], pl->delta[3 * i + k]);
+                        pl->r[3 * i + k] = FMA(-alpha, pl->Ap[3 * i + k], pl->r[3 * i + k]);
                         pl->z[3 * i + k] = pl->pre[3 * i + k] * pl->r[3 * i + k];
                         rb[k] = pl->r[3 * i + k] + b[3 * i + k];
                     }
@@ -542,7 +547,7 @@ int FN(oracle_solve_lm)(int W, int H, REAL *O, REAL *A, const REAL *U, const REA
             if (rho > (REAL)0) beta = rhoNew / rho;
             for (size_t i = 0; i < N; ++i) {
                 if (!FN(act)(pb, (int)i)) continue;
-                for (int k = 0; k < 3; ++k) pl->p[3 * i + k] = pl->z[3 * i + k] + beta * pl->p[3 * i + k];
+                for (int k = 0; k < 3; ++k) pl->p[3 * i + k] = FMA(beta, pl->p[3 * i + k], pl->z[3 * i + k]);
             }
             rho = rhoNew;
             const REAL Q1 = (REAL)sq;
@@ -564,14 +569,14 @@ int FN(oracle_solve_lm)(int W, int H, REAL *O, REAL *A, const REAL *U, const REA
                 for (int k = 0; k < 4; ++k) {
                     if (!FN(edge)(pb, x, y, k, &n)) continue;
                     REAL dx = U[2 * i] - U[2 * n], dy = U[2 * i + 1] - U[2 * n + 1];
-                    REAL qx = -si * dx - ci * dy, qy = ci * dx - si * dy;
-                    REAL mx = e[2 * k] + wr * ((pl->delta[3 * i] - pl->delta[3 * n]) - qx * pl->delta[3 * i + 2]);
-                    REAL my = e[2 * k + 1] + wr * ((pl->delta[3 * i + 1] - pl->delta[3 * n + 1]) - qy * pl->delta[3 * i + 2]);
-                    t = t + mx * mx; t = t + my * my;
+                    REAL qx = FMA(-si, dx, -(ci * dy)), qy = FMA(ci, dx, -(si * dy));
+                    REAL mx = FMA(wr, FMA(-qx, pl->delta[3 * i + 2], pl->delta[3 * i] - pl->delta[3 * n]), e[2 * k]);
+                    REAL my = FMA(wr, FMA(-qy, pl->delta[3 * i + 2], pl->delta[3 * i + 1] - pl->delta[3 * n + 1]), e[2 * k + 1]);
+                    t = FMA(mx, mx, t); t = FMA(my, my, t);
                 }
                 if (FN(fit)(pb, (int)i)) {
-                    REAL mx = e[8] + wf * pl->delta[3 * i], my = e[9] + wf * pl->delta[3 * i + 1];
-                    t = t + mx * mx; t = t + my * my;
+                    REAL mx = FMA(wf, pl->delta[3 * i], e[8]), my = FMA(wf, pl->delta[3 * i + 1], e[9]);
+                    t = FMA(mx, mx, t); t = FMA(my, my, t);
                 }
                 mc += (double)((REAL)0.5 * t);
             }
