@@ -128,10 +128,27 @@ class OptSolver:
         for name, ptr in solver_params.items():                      # OptUtils.h:104-108
             self.lib.Opt_SetSolverParameter(self.state.handle, self.plan, name.encode(), ptr)
 
-    def solve(self, solver_params, problem_params):
-        """OptSolver.h:72-91 (non-profiled branch)."""
+    def solve(self, solver_params, problem_params, profiled=False, iters=None):
+        """OptSolver.h:72-91.  profiled=True is launchProfiledSolve (OptUtils.h:47-64): Init, then Step by Step,
+        appending a (cost, milliseconds) record per Gauss-Newton iteration to `iters` (SolverIteration.h)."""
         self.set_solver_parameters(solver_params)
-        self.lib.Opt_ProblemSolve(self.state.handle, self.plan, problem_params.data())
+        if profiled:
+            import time
+            import torch
+            recs = iters if iters is not None else []
+            self.lib.Opt_ProblemInit(self.state.handle, self.plan, problem_params.data())
+            torch.cuda.synchronize()
+            recs.append((self.lib.Opt_ProblemCurrentCost(self.state.handle, self.plan), 0.0))
+            while True:
+                t0 = time.perf_counter()
+                more = self.lib.Opt_ProblemStep(self.state.handle, self.plan, problem_params.data())
+                if not more:
+                    break
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3
+                recs.append((self.lib.Opt_ProblemCurrentCost(self.state.handle, self.plan), ms))
+        else:
+            self.lib.Opt_ProblemSolve(self.state.handle, self.plan, problem_params.data())
         self.final_cost = self.lib.Opt_ProblemCurrentCost(self.state.handle, self.plan)
         return self.final_cost
 

@@ -370,3 +370,28 @@ def test_lds_tiled_phase_a_is_bit_identical(gpu_state, oracle, tile):
     finally:
         gpu_state.set_tile(-1, -1)
         gpu_state.set_resident(True)
+
+
+def test_profiled_solve_records_cost_per_gn_iteration(gpu_state, oracle):
+    """launchProfiledSolve (OptUtils.h:47-64): the step-by-step solve gives the same unknowns as Opt_ProblemSolve
+    and one (cost, ms) record per Gauss-Newton iteration whose costs are the oracle's"""
+    W, H = 120, 70
+    pb = helpers.random_problem(W, H, seed=2, generic_urshape=False, ncons=40)
+    outs = []
+    for profiled in (False, True):
+        dev = {k: torch.from_numpy(pb[k].copy()).cuda() for k in "OAUCM"}
+        s = opt.OptSolver(gpu_state, (W, H))
+        pp = opt.NamedParameters()
+        for n, k in [("Offset", "O"), ("Angle", "A"), ("UrShape", "U"), ("Constraints", "C"), ("Mask", "M")]:
+            pp.set(n, dev[k])
+        pp.set("w_fitSqrt", 10.0); pp.set("w_regSqrt", 0.1)
+        sp = opt.NamedParameters()
+        sp.set("nIterations", 3); sp.set("lIterations", 25)
+        recs = []
+        s.solve(sp, pp, profiled=profiled, iters=recs)
+        outs.append((dev["O"].cpu().numpy(), recs))
+        s.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    _, _, costs = oracle.solve(pb["O"], pb["A"], pb["U"], pb["C"], pb["M"], 10.0, 0.1, 3, 25, dtype=np.float32, mode=1, trig=1)
+    recs = outs[1][1]
+    assert len(recs) == 4 and [c for c, _ in recs] == list(costs) and all(ms >= 0 for _, ms in recs)
