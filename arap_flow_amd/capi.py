@@ -50,6 +50,7 @@ SYMBOLS = [
     ("ArapFlow_SetTile", _I, [_VP, _I, _I]),
     ("ArapFlow_SolverResidentLaunches", C.c_uint64, [_VP]),
     ("ArapFlow_PlanResidentLaunches", C.c_uint64, [_VP]),
+    ("ArapFlow_ResidentFailed", _I, [_VP]),
     ("ArapFlow_SolverStamps", _I, [_VP, _VP]),
     ("ArapFlow_WarpScratchBytes", C.c_uint64, [_U, _U]),
     ("ArapFlow_Warp", _I, [_VP, _U, _U, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -58,6 +58,9 @@ struct PlanDev {
     float2 *bO, *CtCO, *SSqO, *AdO;
     float *bA, *CtCA, *SSqA, *AdA;
     double* lmred;           // [lIterations + 2][NSHARD]: q after iteration l at l+1 (Q0 at 0), model cost last
+    // error word of the resident kernel (arap_resident.h), NULL when the plan has none: once it is set the step's
+    // update is skipped so that the host can redo the step on the two-kernel path from unchanged unknowns
+    const unsigned* res_err;
 };
 
 // ---- cos/sin: same operation list as oracle/arap_oracle.c:arap_sincos_spec ----------------------

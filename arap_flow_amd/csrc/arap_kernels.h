@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_pcg_b4(PlanDev pd, int l)
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd)
 {
     const VIdx v = vidx(pd);
+    if (pd.res_err && *pd.res_err) return;          // the resident kernel gave up: leave X as it was (see PlanDev)
     if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
     if (!v.in || !(pd.flags[v.g] & F_ACT)) return;
     const Slot sl = pd.slots[v.b];

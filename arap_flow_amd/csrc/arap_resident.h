@@ -60,6 +60,7 @@ struct ResDev {
     int groups;                 // 16, 8, 4, 2 or 1
     int wgs;                    // workgroups per group = RES_WGS / groups
     int allow_fast;             // 0: always use the write-through (placement independent) store flavour
+    int force_fail;             // test hook (ARAPOPT_FORCE_RES_FAIL=1): behave as if a group wait had timed out
     unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][8] summed s_memrealtime ticks
 };
 
@@ -199,6 +200,12 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         rank = blockIdx.x / rd.groups;
     }
     if (g >= rd.nframes) return;                       // whole groups leave together
+    // A previous launch (or the test hook) gave up: do nothing, the host redoes the step on the two-kernel path.
+    if (rd.force_fail) {
+        if (threadIdx.x == 0) atomicExch(rd.err, 0xDEADFFFFu);
+        return;
+    }
+    if (__hip_atomic_load(rd.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int b = rd.slot0 + g;
     const int wgs = rd.wgs;
     const int W = pd.W, H = pd.H;

@@ -83,6 +83,7 @@ struct Opt_State {
     KernelTimer ktimer;
     bool use_graph = true;
     bool use_resident = true;   // ArapFlow_SetResident
+    bool resident_failed = false;   // a resident launch timed out once (GPU shared with another process?): path switched off
     int tile = -1;              // ArapFlow_SetTile: phase-A variant of the two-kernel path; -1 = choose per solve
 };
 
@@ -204,7 +205,12 @@ static void plan_enable_resident(Opt_Plan* p)
     p->rd.tilelist = (const int*)c; c += sz_tl;            // exactly this 16-byte-multiple block
     p->rd.ntiles = (const int*)c; c += sz_nt;
     p->rd.err = (unsigned*)c;
+    p->pd.res_err = p->rd.err;
     p->rd.stamps = nullptr;
+    {
+        const char* ff = getenv("ARAPOPT_FORCE_RES_FAIL");      // test hook
+        p->rd.force_fail = (ff && ff[0] == '1') ? 1 : 0;
+    }
     {
         const char* nf = getenv("ARAPOPT_NO_XCD_FAST");
         p->rd.allow_fast = (nf && nf[0] == '1') ? 0 : 1;
@@ -278,13 +284,29 @@ static int plan_resident_groups(const Opt_Plan* p)
     return groups;
 }
 
-static void plan_check_resident_error(Opt_Plan* p)
+// Did a resident launch of this plan give up (a bounded group wait timed out: its 512 workgroups were not all
+// resident, e.g. because another process uses the GPU)?  Then the step's update was skipped on the device
+// (k_gn_update), the error word is cleared, the resident path is switched off for this state and the caller redoes
+// the work on the two-kernel path.  Requires a synchronised stream.
+static bool plan_resident_failed(Opt_Plan* p)
 {
-    if (!p->res_capable || p->res_launches == 0) return;
+    if (!p->res_capable || p->res_launches == 0) return false;
     unsigned e = 0;
     HC(hipMemcpy(&e, p->rd.err, sizeof(e), hipMemcpyDeviceToHost));
-    if (e != 0) {
-        fprintf(stderr, "arapopt: resident PCG kernel timed out at a group barrier (code 0x%08x)\n", e);
+    if (e == 0) return false;
+    if (!p->st->resident_failed)
+        fprintf(stderr, "arapopt: resident PCG kernel gave up at a group wait (code 0x%08x); is the GPU shared? "
+                        "Falling back to the two-kernel path for this state.\n", e);
+    p->st->resident_failed = true;
+    p->st->use_resident = false;
+    HC(hipMemset((void*)p->rd.err, 0, sizeof(unsigned)));
+    return true;
+}
+
+static void plan_check_resident_error(Opt_Plan* p)
+{
+    if (plan_resident_failed(p)) {        // reached only if a caller consumed results without the checks below
+        fprintf(stderr, "arapopt: resident PCG failure detected after results were consumed\n");
         exit(3);
     }
 }
@@ -517,7 +539,13 @@ static int plan_step(Opt_Plan* p)
 {
     if (p->sp.nIter < p->sp.nIterations) {
         plan_upload_slots(p);
+        const bool used_res = plan_resident_eligible(p);
         plan_gn_step(p);
+        if (used_res && !p->res_frames) {
+            // drop-in plan: the caller may read the unknowns right after this Step, so make sure it happened
+            HC(hipStreamSynchronize(p->st->stream));
+            if (plan_resident_failed(p)) plan_gn_step(p);          // X untouched: redo on the two-kernel path
+        }
         plan_cost(p, p->sp.nIter + 1);
         if (p->st->verbosity > 0) {
             const double a = plan_read_cost(p, 0, p->sp.nIter), b = plan_read_cost(p, 0, p->sp.nIter + 1);
@@ -1130,13 +1158,21 @@ int ArapFlow_SolverSolve(ArapFlow_Solver* s, unsigned nframes, unsigned numIter,
     p->sp.nIterations = (int)nIterations;
     p->sp.lIterations = (int)lIterations;
     const dim3 g1((s->N + 255) / 256, 1, nframes);
-    // preSingleSolve = resetGPU (CombinedSolver.h:191-193)
-    hipLaunchKernelGGL(k_frame_reset, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N);
-    for (unsigned i = 0; i < numIter; ++i) {
-        const float alpha = (float)(i + 1) / (float)numIter;          // CombinedSolver.h:199-201
-        hipLaunchKernelGGL(k_frame_ramp, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N, alpha);
-        plan_init(p);
-        while (plan_step(p) != 0) {}
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool used_res = plan_resident_eligible(p);
+        // preSingleSolve = resetGPU (CombinedSolver.h:191-193)
+        hipLaunchKernelGGL(k_frame_reset, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N);
+        for (unsigned i = 0; i < numIter; ++i) {
+            const float alpha = (float)(i + 1) / (float)numIter;          // CombinedSolver.h:199-201
+            hipLaunchKernelGGL(k_frame_ramp, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N, alpha);
+            plan_init(p);
+            while (plan_step(p) != 0) {}
+        }
+        if (!used_res) break;
+        // the resident path needs all its workgroups co-resident; if a launch gave up (GPU shared with another
+        // process), redo the whole schedule on the two-kernel path: one synchronisation per solve call
+        HC(hipStreamSynchronize(st->stream));
+        if (!plan_resident_failed(p)) break;
     }
     s->last_cost_index = p->sp.nIter;
     s->last_n = nframes;
@@ -1197,6 +1233,7 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg, uint64_t* active, ui
 
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s) { return s ? s->plan->res_launches : 0; }
 uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan) { return plan ? plan->res_launches : 0; }
+int ArapFlow_ResidentFailed(Opt_State* state) { return state && state->resident_failed ? 1 : 0; }
 
 // diagnostic (ARAPOPT_STAMPS=1): copy the [256][8] phase-time table of the LAST resident launch
 int ArapFlow_SolverStamps(ArapFlow_Solver* s, uint64_t* out)

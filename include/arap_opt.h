@@ -194,6 +194,10 @@ uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s);
  * the active tiles fit; the Mask/UrShape buffers analysed at Init must then stay the ones passed to the Steps
  * (other buffers -> general two-kernel path).  Counts resident launches enqueued/captured for this plan. */
 uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan);
+/* The resident kernel needs its 512 workgroups co-resident.  If a launch gives up at a bounded group wait (e.g.
+ * another process is using the GPU), the step's update is skipped on the device, the work is redone on the
+ * two-kernel path (same results) and the resident path stays off for this state; this returns 1 from then on. */
+int ArapFlow_ResidentFailed(Opt_State* state);
 /* Diagnostic only (env ARAPOPT_STAMPS=1 selects an instrumented build of the resident kernel): copies
  * out[512][8] = per workgroup {phase A, wait 1, phase B, wait 2, update} summed 100 MHz ticks of the
  * last resident launch, tiles per workgroup, halo cells.  Returns -1 when stamps are off. */
