@@ -3,9 +3,9 @@
 // Why: at 854x480 one PCG iteration moves at most 65 MB, ~10 us at HBM speed, and a DAVIS-shaped frame
 // (25 % of the vertices active) 16 MB; the two dependent global reductions per iteration make a
 // kernel-per-phase solve latency bound (profiles/r01_v1_*: 20-27 us per kernel for 8 frames, 75 % of the
-// workgroups empty).  Here every frame of the batch is solved by a GROUP of 64..512 workgroups (256
-// threads, TWO workgroups per CU so one computes while the other waits) that stays resident for all
-// lIterations iterations:
+// workgroups empty).  Here every frame of the batch is solved by a GROUP of workgroups (256 threads, TWO
+// workgroups per CU so one computes while the other waits; the host sizes the group by the frame's
+// active tiles, ResWg below) that stays resident for all lIterations iterations:
 //   * r, delta, M^-1_A, flags and the transient Ap live in registers (9 tile slots of 64x4 vertices per
 //     workgroup, one vertex per lane per slot),
 //   * the search direction p and cos/sin(A) live in LDS as 66x6 halo'd tiles (the stencil reads
@@ -18,9 +18,9 @@
 // Inter-workgroup visibility follows cdna_hip_programming.md Guideline 16 (R1/R2): handed-off bytes
 // are written with agent-scope (sc1, write-through) stores, every storing wave drains vmcnt(0), the
 // workgroup barriers, ONE lane publishes {tag, value} granules, consumers poll them with sc1 loads
-// and read the payload with sc1 loads only.  Correctness never depends on placement; blockIdx & 7
-// as group id merely tends to keep a group on one XCD.  Every spin is bounded; a timeout sets an error
-// word that the host turns into a hard failure.
+// and read the payload with sc1 loads only.  Correctness never depends on placement; dealing a group
+// workgroups of equal blockIdx & 7 merely tends to keep it on one XCD.  Every spin is bounded; a timeout
+// sets an error word and the host redoes the step on the two-kernel path.
 //
 // Arithmetic: the same float32 operation list as k_pcg_a / k_pcg_b (and the CPU oracle), for the
 // pixel-grid UrShape the frame solver always uses (CombinedSolver.h:207-221): d_s = U(c)-U(n) = -s.
@@ -31,7 +31,7 @@ namespace arap {
 
 constexpr int RES_WGS = 512;             // workgroups per launch: TWO per CU of an MI355X (256 CUs), so that one
                                          // workgroup computes while its CU-mate (another frame's group) waits
-constexpr int RES_MAX_GROUPS = 16;       // frames in flight per launch: 16, 8, 4, 2 or 1 groups of 32..512 workgroups
+constexpr int RES_MAX_GROUPS = 16;       // most equal groups ARAPOPT_RES_GROUPS may force (experiments)
 constexpr int RES_THREADS = 256;         // 4 wavefronts = the 4 rows of a 64x4 tile, one per SIMD
 constexpr int RES_SLOTS = 9;             // tile slots per workgroup (register arrays, fully unrolled)
 constexpr int RES_TILES_PER_WG = RES_SLOTS;
@@ -50,15 +50,21 @@ constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / co
 #endif
 constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
 
+// One entry per workgroup of a launch, written by the host (arapopt.hip: plan_resident_pack): which solve the
+// workgroup works on, its rank in that solve's group, the group's size and where the group's granules start.
+struct ResWg {
+    int slot;                   // batch slot of the solve, -1: this workgroup is idle in this launch
+    int rank;                   // 0 .. wgs-1
+    int wgs;                    // workgroups of the group
+    int gran;                   // first granule (in u64 units) of the group: [2 parity][wgs][2]
+};
+
 struct ResDev {
     const int* tilelist;        // [batch][RES_MAX_TILES] linear tile index (ty * tilesX + tx) of active tiles
     const int* ntiles;          // [batch]
-    unsigned long long* gran;   // [groups][2 parity][wgs][2]  {tag << 32 | 32 value bits}; groups*wgs = RES_WGS
+    unsigned long long* gran;   // [2 * RES_WGS * 2]  {tag << 32 | 32 value bits}
     unsigned* err;              // [1] 0 = ok
-    int nframes;                // frames of this launch, <= groups
-    int slot0;                  // first batch slot of this launch
-    int groups;                 // 16, 8, 4, 2 or 1
-    int wgs;                    // workgroups per group = RES_WGS / groups
+    const ResWg* wgmap;         // [RES_WGS] of this launch
     int allow_fast;             // 0: always use the write-through (placement independent) store flavour
     int force_fail;             // test hook (ARAPOPT_FORCE_RES_FAIL=1): behave as if a group wait had timed out
     unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][8] summed s_memrealtime ticks
@@ -186,28 +192,21 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     unsigned long long tA = 0, tS1 = 0, tB = 0, tS2 = 0, tU = 0, t0 = 0, t1 = 0;
 #define RES_STAMP(acc) do { if (STAMPS) { t1 = __builtin_amdgcn_s_memrealtime(); acc += t1 - t0; t0 = t1; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // Group of this workgroup.  Speed only (never correctness): workgroups are dealt round-robin over the 8
-    // XCDs, so blockIdx & 7 labels the XCD.  With >= 8 groups a group is the j-th block of `wgs` workgroups of
-    // one XCD: it stays on that XCD (same-XCD fast path) and, with 16 groups, the two workgroups that share a CU
-    // (local indices j and j + 32) belong to different frames, so one computes while the other waits.
-    int g, rank;
-    if (rd.groups >= 8) {
-        const int j = blockIdx.x >> 3;
-        g = (blockIdx.x & 7) + 8 * (j / rd.wgs);
-        rank = j % rd.wgs;
-    } else {
-        g = blockIdx.x % rd.groups;
-        rank = blockIdx.x / rd.groups;
-    }
-    if (g >= rd.nframes) return;                       // whole groups leave together
+    // Group of this workgroup: dealt by the host (ResWg).  Speed only (never correctness): workgroups are dealt
+    // round-robin over the 8 XCDs, so the host gives a group of <= 64 workgroups a run of blockIdx values with
+    // the same blockIdx & 7: it stays on that XCD (same-XCD fast path), and since the two workgroups that share a
+    // CU have local indices j and j + 32, several small groups on one XCD overlap each other's waits.
+    const ResWg me = rd.wgmap[blockIdx.x];
+    if (me.slot < 0) return;                           // whole groups leave together
+    const int rank = me.rank;
     // A previous launch (or the test hook) gave up: do nothing, the host redoes the step on the two-kernel path.
     if (rd.force_fail) {
         if (threadIdx.x == 0) atomicExch(rd.err, 0xDEADFFFFu);
         return;
     }
     if (__hip_atomic_load(rd.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    const int b = rd.slot0 + g;
-    const int wgs = rd.wgs;
+    const int b = me.slot;
+    const int wgs = me.wgs;
     const int W = pd.W, H = pd.H;
     const size_t gb = (size_t)b * pd.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,10 +217,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     float* bcast = moLUT + 12;                                            // 2 floats + nhalo (int) + pad
     int* nhalo = (int*)(bcast + 2);
     double* wsum = (double*)(bcast + 4);                                  // 4 doubles
-    unsigned long long* gran_group = rd.gran + (size_t)g * 2 * wgs * 2;
+    unsigned long long* gran_group = rd.gran + me.gran;
 
     const int nt = rd.ntiles[b];
-    const int tp = (nt + wgs - 1) / wgs;                                  // tiles per workgroup (<= 16)
+    // this workgroup's run of the frame's active-tile list: nt tiles dealt evenly, the first nt % wgs ranks
+    // take one more (the two workgroups of a CU run in lockstep, so an even deal shortens every phase)
+    const int tbase_n = nt / wgs, textra = nt - tbase_n * wgs;
+    const int tp = tbase_n + (rank < textra ? 1 : 0);                     // tiles of this workgroup (<= 9)
+    const int tfirst = rank * tbase_n + (rank < textra ? rank : textra);
     const int* tl = rd.tilelist + (size_t)b * RES_MAX_TILES;
     float wr2, wf2;
     {
@@ -256,13 +259,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #pragma unroll
     for (int j = 0; j < RES_SLOTS; ++j) {
         const int k = j;                               // local tile
-        const int gt = rank * tp + k;                  // position in the frame's active-tile list
+        const int gt = tfirst + k;                     // position in the frame's active-tile list
         rx[j] = ry[j] = ra[j] = 0.f; dx_[j] = dy_[j] = da_[j] = 0.f;
         apx[j] = apy[j] = apa[j] = 0.f;
         unsigned f = 0;
         float mA = 0.f;
         int x0 = -1, y0 = -1;
-        if (k < tp && gt < nt) {
+        if (k < tp) {
             const int tile = tl[gt];
             const int ty = tile / pd.tilesX, tx = tile - ty * pd.tilesX;
             x0 = tx * TILE_X; y0 = ty * TILE_Y;

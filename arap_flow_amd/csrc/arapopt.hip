@@ -10,6 +10,7 @@
 // solverGPUGaussNewton.t:1058-1091, and a blocking read-back per step, :790-797).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -115,13 +116,17 @@ struct Opt_Plan {
     // graph of one GN step, keyed by (lIterations, nb)
     hipGraphExec_t gexec = nullptr;
     hipGraph_t graph = nullptr;
-    int g_l = -1, g_nb = -1, g_res = -1;   // g_res: 0 = two-kernel path, else the resident group count
+    int g_l = -1, g_nb = -1, g_res = -1;   // g_res > 0: resident launches per step, < 0: two-kernel phase-A variant
     // resident PCG (arap_resident.h): only for the frame solver (pixel-grid UrShape, host-known masks)
     bool res_capable = false;       // device has 256 CUs and the kernel fits one workgroup per CU
     bool res_frames = false;        // plan is driven by ArapFlow_Solver
     ResDev rd{};
     void* res_block = nullptr;
     std::vector<int> h_ntiles;
+    ResWg* d_wgmap = nullptr;       // [batch][RES_WGS]: one table per resident launch of a GN step
+    std::vector<ResWg> h_wgmap;     // what d_wgmap holds
+    int res_sets = 0;               // resident launches per GN step
+    int res_inflight = 0;           // solves of the fullest launch (diagnostic)
     unsigned res_launches = 0;
     // drop-in (Opt_*) plans: result of the Init-time analysis (k_analyse) of the caller's Mask / UrShape
     bool opt_res_ok = false;
@@ -198,13 +203,15 @@ static void plan_enable_resident(Opt_Plan* p)
     const size_t sz_tl = align_up((size_t)p->batch * RES_MAX_TILES * sizeof(int), 256);
     const size_t sz_nt = align_up((size_t)p->batch * sizeof(int), 256);
     const size_t sz_gr = align_up((size_t)2 * RES_WGS * 2 * 8, 256);
-    HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256));
-    HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256, st->stream));
+    const size_t sz_map = align_up((size_t)p->batch * RES_WGS * sizeof(ResWg), 256);
+    HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map));
+    HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map, st->stream));
     char* c = (char*)p->res_block;
     p->rd.gran = (unsigned long long*)c; c += sz_gr;       // granules first: the per-launch memset zeroes
     p->rd.tilelist = (const int*)c; c += sz_tl;            // exactly this 16-byte-multiple block
     p->rd.ntiles = (const int*)c; c += sz_nt;
-    p->rd.err = (unsigned*)c;
+    p->rd.err = (unsigned*)c; c += 256;
+    p->d_wgmap = (ResWg*)c;
     p->pd.res_err = p->rd.err;
     p->rd.stamps = nullptr;
     {
@@ -270,18 +277,117 @@ static bool plan_resident_eligible(const Opt_Plan* p)
     return true;
 }
 
-// frames in flight per resident launch: the most groups whose workgroups can hold the largest frame
-static int plan_resident_groups(const Opt_Plan* p)
+// Deal the solves of the current batch to resident launches and their 512 workgroups (ResWg tables).
+//  * A solve of nt active tiles needs ceil(nt / 9) workgroups.  If every solve fits the 64 workgroups that land on
+//    one XCD (blockIdx & 7 equal, local index blockIdx >> 3), the solves are bin-packed into the 8 XCDs of as few
+//    launches as first-fit-decreasing needs, spread evenly over those bins (least-loaded first), and every group is
+//    then widened to use its bin's spare workgroups (fewer tiles per workgroup = shorter phases).  Groups of one
+//    bin take consecutive local indices, so the two workgroups of a CU (j, j + 32) usually serve different solves.
+//  * Otherwise (a solve spans XCDs) the launch is cut into 4, 2 or 1 equal groups, group = blockIdx % groups.
+// Returns the number of launches; fills `map` ([launches][RES_WGS]) and `inflight_out` when given.
+static int resident_deal(const Opt_Plan* p, int nb, std::vector<ResWg>* map_out, int* inflight_out)
 {
+    std::vector<int> need(nb);
     int mx = 1;
-    for (int b = 0; b < p->nb; ++b) mx = p->h_ntiles[b] > mx ? p->h_ntiles[b] : mx;
-    int groups = RES_MAX_GROUPS;
-    while (groups > 1 && (RES_WGS / groups) * RES_TILES_PER_WG < mx) groups >>= 1;
-    // Fewer frames than groups: narrow groups still win (a 64-workgroup group sits on one XCD and takes the
-    // same-XCD fast path; a wide group spans XCDs and pays write-through publishing), so do not widen.
-    const char* fg = getenv("ARAPOPT_RES_GROUPS");               // experiments only
-    if (fg && atoi(fg) > 0 && atoi(fg) <= groups) groups = atoi(fg);
-    return groups;
+    for (int b = 0; b < nb; ++b) {
+        need[b] = (p->h_ntiles[b] + RES_TILES_PER_WG - 1) / RES_TILES_PER_WG;
+        if (need[b] < 1) need[b] = 1;
+        mx = need[b] > mx ? need[b] : mx;
+    }
+    std::vector<ResWg> map;
+    int nsets = 0, inflight = 0;
+    const ResWg idle = {-1, 0, 0, 0};
+    int forced = 0;
+    {
+        const char* fg = getenv("ARAPOPT_RES_GROUPS");           // experiments only: equal groups as below
+        if (fg && atoi(fg) > 0) forced = atoi(fg);
+    }
+    const int XW = RES_WGS / 8;                                  // workgroups per XCD
+    if (mx <= XW && !forced) {
+        std::vector<int> order(nb);
+        for (int b = 0; b < nb; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return need[a] > need[c]; });
+        // (1) number of launches: first fit decreasing
+        std::vector<int> load;
+        for (int b : order) {
+            size_t k = 0;
+            while (k < load.size() && load[k] + need[b] > XW) ++k;
+            if (k == load.size()) load.insert(load.end(), 8, 0);
+            load[k] += need[b];
+        }
+        nsets = (int)load.size() / 8;
+        // (2) spread: least-loaded bin that still fits; keep the first-fit deal if that ever fails
+        std::vector<std::vector<int>> bins(load.size());
+        std::vector<int> l2(load.size(), 0);
+        bool ok = true;
+        for (int b : order) {
+            int best = -1;
+            for (size_t k = 0; k < l2.size(); ++k)
+                if (l2[k] + need[b] <= XW && (best < 0 || l2[k] < l2[best])) best = (int)k;
+            if (best < 0) { ok = false; break; }
+            l2[best] += need[b];
+            bins[best].push_back(b);
+        }
+        if (!ok) {
+            for (auto& v : bins) v.clear();
+            std::fill(l2.begin(), l2.end(), 0);
+            for (int b : order) {
+                size_t k = 0;
+                while (l2[k] + need[b] > XW) ++k;
+                l2[k] += need[b];
+                bins[k].push_back(b);
+            }
+        }
+        map.assign((size_t)nsets * RES_WGS, idle);
+        for (int set = 0; set < nsets; ++set) {
+            int ordinal = 0, count = 0;                          // workgroups / solves dealt in this launch
+            for (int x = 0; x < 8; ++x) {
+                const std::vector<int>& v = bins[(size_t)set * 8 + x];
+                const int used = l2[(size_t)set * 8 + x];
+                int j = 0;
+                for (int b : v) {
+                    const int wgs = XW * need[b] / used;         // >= need[b]; the widths of a bin sum to <= 64
+                    for (int r = 0; r < wgs; ++r, ++j)
+                        map[(size_t)set * RES_WGS + (size_t)j * 8 + x] = ResWg{b, r, wgs, 4 * ordinal};
+                    ordinal += wgs;
+                    ++count;
+                }
+            }
+            inflight = count > inflight ? count : inflight;
+        }
+    } else {
+        int groups = 4;
+        while (groups > 1 && RES_WGS / groups < mx) groups >>= 1;
+        if (forced && forced <= RES_MAX_GROUPS && (RES_WGS / forced) >= mx && (RES_WGS % forced) == 0) groups = forced;
+        const int wgs = RES_WGS / groups;
+        nsets = (nb + groups - 1) / groups;
+        map.assign((size_t)nsets * RES_WGS, idle);
+        for (int set = 0; set < nsets; ++set)
+            for (int i = 0; i < RES_WGS; ++i) {
+                int g, rank;
+                if (groups >= 8) { const int j = i >> 3; g = (i & 7) + 8 * (j / wgs); rank = j % wgs; }
+                else { g = i % groups; rank = i / groups; }
+                const int b = set * groups + g;
+                if (b < nb) map[(size_t)set * RES_WGS + i] = ResWg{b, rank, wgs, 4 * g * wgs};
+            }
+        inflight = nb < groups ? nb : groups;
+    }
+    if (map_out) map_out->swap(map);
+    if (inflight_out) *inflight_out = inflight;
+    return nsets;
+}
+
+// Deal the current batch; true if the tables changed (the caller re-uploads them and drops the captured graph).
+static bool plan_resident_pack(Opt_Plan* p)
+{
+    std::vector<ResWg> map;
+    const int nsets = resident_deal(p, p->nb, &map, &p->res_inflight);
+    const bool same = nsets == p->res_sets && map.size() == p->h_wgmap.size() &&
+                      memcmp(map.data(), p->h_wgmap.data(), map.size() * sizeof(ResWg)) == 0;
+    if (same) return false;
+    p->h_wgmap.swap(map);
+    p->res_sets = nsets;
+    return true;
 }
 
 // Did a resident launch of this plan give up (a bounded group wait timed out: its 512 workgroups were not all
@@ -443,11 +549,8 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
         // all L iterations in one launch, state on chip (arap_resident.h).  Granule tags restart at 1
         // in every launch, so the granule block is zeroed first (cdna guide G16 "re-initialise every call").
         ResDev rd = p->rd;
-        rd.groups = plan_resident_groups(p);
-        rd.wgs = RES_WGS / rd.groups;
-        for (int s0 = 0; s0 < p->nb; s0 += rd.groups) {
-            rd.slot0 = s0;
-            rd.nframes = p->nb - s0 < rd.groups ? p->nb - s0 : rd.groups;
+        for (int set = 0; set < p->res_sets; ++set) {
+            rd.wgmap = p->d_wgmap + (size_t)set * RES_WGS;
             HC(hipMemsetAsync(rd.gran, 0, (size_t)2 * RES_WGS * 2 * 8, s));
             if (rd.stamps)
                 hipLaunchKernelGGL(k_pcg_resident<true>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
@@ -472,12 +575,20 @@ static void plan_gn_step(Opt_Plan* p)
 {
     Opt_State* st = p->st;
     const bool graph_ok = st->use_graph && !st->timing;
+    const bool res = plan_resident_eligible(p);
+    if (res && plan_resident_pack(p)) {
+        // new deal of solves to workgroups (the frames' active-tile counts changed): upload the tables (pageable
+        // source: staged before the call returns; stream ordered behind earlier launches) and re-capture
+        HC(hipMemcpyAsync(p->d_wgmap, p->h_wgmap.data(), p->h_wgmap.size() * sizeof(ResWg), hipMemcpyHostToDevice,
+                          st->stream));
+        plan_drop_graph(p);
+    }
     if (!graph_ok) {
         enqueue_gn_step(p, st->stream);
         return;
     }
-    // the captured resident launches bake in the group count, which follows the frames' active-tile counts
-    const int res_now = plan_resident_eligible(p) ? plan_resident_groups(p) : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p));
+    // the captured launches bake in the path (resident: number of launches; two-kernel: phase-A variant)
+    const int res_now = res ? p->res_sets : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p));
     if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
@@ -1233,6 +1344,24 @@ int ArapFlow_SolverStats(ArapFlow_Solver* s, uint64_t* pcg, uint64_t* active, ui
 
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s) { return s ? s->plan->res_launches : 0; }
 uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan) { return plan ? plan->res_launches : 0; }
+int ArapFlow_SolverLaunchesFor(ArapFlow_Solver* s, unsigned nframes)
+{
+    if (!s || nframes == 0 || nframes > (unsigned)s->plan->batch) return -1;
+    Opt_Plan* p = s->plan;
+    const int keep = p->nb;
+    p->nb = (int)nframes;                              // eligibility looks at the first nb slots
+    const int sets = plan_resident_eligible(p) ? resident_deal(p, (int)nframes, nullptr, nullptr) : 0;
+    p->nb = keep;
+    return sets;
+}
+int ArapFlow_SolverResidentLayout(ArapFlow_Solver* s, int* launches_per_step, int* solves_in_flight)
+{
+    if (!s) return -1;
+    const bool res = plan_resident_eligible(s->plan) && s->plan->res_sets > 0;
+    if (launches_per_step) *launches_per_step = res ? s->plan->res_sets : 0;
+    if (solves_in_flight) *solves_in_flight = res ? s->plan->res_inflight : 0;
+    return 0;
+}
 int ArapFlow_ResidentFailed(Opt_State* state) { return state && state->resident_failed ? 1 : 0; }
 
 // diagnostic (ARAPOPT_STAMPS=1): copy the [256][8] phase-time table of the LAST resident launch

@@ -3,7 +3,7 @@
 //   ./arap_deform RGB Mask Constraint Flow warped_RGB warped_Mask        (one frame)
 //   ./arap_deform listfile                                               (six paths per line)
 // The reference keeps one CombinedSolver (one Opt plan) and feeds it frame after frame (main.cpp:223-238);
-// here consecutive frames of equal size are handed to the device-resident batched solver eight at a time
+// here consecutive frames of equal size are handed to the device-resident batched solver, as many as fit one launch
 // (ArapFlow_Solver = CombinedSolver on the GPU: reset, 19-step constraint ramp, 8 GN x 400 PCG, flow, rasteriser).
 #include <cstdio>
 #include <cstdlib>
@@ -128,7 +128,10 @@ int main(int argc, const char* argv[])
         Opt_ProblemDelete(state, pr);
     }
     const unsigned numIter = 19, nonLinearIter = 8, linearIter = 400;    // main.cpp:215-221
-    const unsigned maxBatch = 8;
+    // Frames per solve call: the library gives every solve a group of the resident launch's workgroups sized by its
+    // active tiles and a launch costs the same however full it is, so frames join a batch while they still fit ONE
+    // launch (ArapFlow_SolverLaunchesFor); minFill frames per call when the resident kernel does not apply.
+    const unsigned maxBatch = 32, minFill = 8;
 
     ArapFlow_Solver* solver = nullptr;
     int sw = 0, sh = 0;
@@ -137,14 +140,6 @@ int main(int argc, const char* argv[])
         std::vector<Frame> batch(1);
         if (!load_frame(lines[i], batch[0])) return 1;
         const int w = batch[0].rgb.w, h = batch[0].rgb.h;
-        size_t j = i + 1;
-        while (j < lines.size() && batch.size() < maxBatch) {
-            Frame f;
-            if (!load_frame(lines[j], f)) return 1;
-            if (f.rgb.w != w || f.rgb.h != h) break;                     // next batch starts here (re-read then)
-            batch.push_back(std::move(f));
-            ++j;
-        }
         if (w != sw || h != sh) {
             if (solver) {
                 printf("Warning: Input image has different size to one in the prebuilt plan.\n"
@@ -156,10 +151,23 @@ int main(int argc, const char* argv[])
             if (!solver) return 1;
             sw = w; sh = h;
         }
-        for (size_t b = 0; b < batch.size(); ++b)                         // addImage
-            if (ArapFlow_SolverSetFrame(solver, (unsigned)b, batch[b].rgb.rgb.data(), batch[b].mask_red.data(),
-                                        batch[b].constraints.data(), (unsigned)(batch[b].constraints.size() / 4), 0) != 0)
-                return 1;
+        auto add_image = [&](unsigned b, const Frame& f) {               // addImage
+            return ArapFlow_SolverSetFrame(solver, b, f.rgb.rgb.data(), f.mask_red.data(), f.constraints.data(),
+                                           (unsigned)(f.constraints.size() / 4), 0) == 0;
+        };
+        if (!add_image(0, batch[0])) return 1;
+        size_t j = i + 1;
+        while (j < lines.size() && batch.size() < maxBatch) {
+            Frame f;
+            if (!load_frame(lines[j], f)) return 1;
+            if (f.rgb.w != w || f.rgb.h != h) break;                     // next batch starts here (re-read then)
+            const unsigned b = (unsigned)batch.size();
+            if (!add_image(b, f)) return 1;
+            const int launches = ArapFlow_SolverLaunchesFor(solver, b + 1);
+            if (launches > 1 || (launches == 0 && b >= minFill)) break;  // this frame opens the next batch
+            batch.push_back(std::move(f));
+            ++j;
+        }
         ArapFlow_SolverSolve(solver, (unsigned)batch.size(), numIter, nonLinearIter, linearIter);   // solveAll
         ArapFlow_SolverWarp(solver, (unsigned)batch.size());
         std::vector<float> flow((size_t)w * h * 2);

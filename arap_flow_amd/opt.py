@@ -299,6 +299,10 @@ class FrameSolver:
         if rc != 0:
             raise ValueError("ArapFlow_SolverSetFrame: bad arguments")
 
+    def launches_for(self, nframes):
+        """resident launches per Gauss-Newton step a solve of slots [0, nframes) would take (0: two-kernel path)"""
+        return int(self.lib.ArapFlow_SolverLaunchesFor(self.h, int(nframes)))
+
     def solve(self, nframes=None, num_iter=19, non_linear_iter=8, linear_iter=400):
         n = self.batch if nframes is None else nframes
         rc = self.lib.ArapFlow_SolverSolve(self.h, n, num_iter, non_linear_iter, linear_iter)
@@ -329,8 +333,11 @@ class FrameSolver:
     def stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self.lib.ArapFlow_SolverStats(self.h, C.byref(a), C.byref(b), C.byref(c))
+        ls, fl = C.c_int(0), C.c_int(0)
+        self.lib.ArapFlow_SolverResidentLayout(self.h, C.byref(ls), C.byref(fl))
         return dict(pcg_iterations_per_frame=a.value, active_vertices=b.value, grid_vertices=c.value,
-                    resident_launches=int(self.lib.ArapFlow_SolverResidentLaunches(self.h)))
+                    resident_launches=int(self.lib.ArapFlow_SolverResidentLaunches(self.h)),
+                    resident_launches_per_step=ls.value, resident_solves_in_flight=fl.value)
 
     def close(self):
         if self.h:

@@ -59,22 +59,20 @@ def save_mask(mask, path):
     Image.fromarray(np.ascontiguousarray(mask) > 0).save(path)
 
 
-def deform_list(state, lines, num_iter=19, non_linear_iter=8, linear_iter=400, max_batch=8, verbose=True):
-    """arap_deform over a list (main.cpp:223-238): frames of equal size are solved `max_batch` at a time."""
+FILL_MIN, FILL_MAX = 8, 32     # frames per solve call: at least / at most (see deform_list)
+
+
+def deform_list(state, lines, num_iter=19, non_linear_iter=8, linear_iter=400, max_batch=FILL_MAX, verbose=True):
+    """arap_deform over a list (main.cpp:223-238).  Frames of equal size are solved together: the library gives
+    every solve a group of the resident launch's workgroups sized by its active tiles, and a launch costs the same
+    however full it is, so frames are added to a batch while they still fit ONE launch (8 DAVIS-shaped 854x480
+    frames, ~21 --multseg segment solves); FILL_MIN frames per call when the resident path does not apply."""
     from . import opt
     i = 0
     solver, size = None, None
     while i < len(lines):
         rgb0 = load_rgb(lines[i][0])
         H, W = rgb0.shape[:2]
-        batch = [(lines[i], rgb0)]
-        j = i + 1
-        while j < len(lines) and len(batch) < max_batch:
-            rgb = load_rgb(lines[j][0])
-            if rgb.shape[:2] != (H, W):
-                break
-            batch.append((lines[j], rgb))
-            j += 1
         if size != (W, H):
             if solver is not None:
                 if verbose:
@@ -84,15 +82,28 @@ def deform_list(state, lines, num_iter=19, non_linear_iter=8, linear_iter=400, m
                 solver.close()
             solver = opt.FrameSolver(state, W, H, batch=max_batch)
             size = (W, H)
-        for b, (ln, rgb) in enumerate(batch):
+        batch = []
+        j = i
+        while j < len(lines) and len(batch) < max_batch:
+            ln = lines[j]
+            rgb = rgb0 if j == i else load_rgb(ln[0])
+            if rgb.shape[:2] != (H, W):
+                break
             mask = load_mask_red(ln[1])
             if mask.shape != (H, W):
                 raise ValueError("mask %s has another size than %s" % (ln[1], ln[0]))
             cons = opt.load_constraints(ln[2])
+            b = len(batch)
             solver.set_frame(b, mask, cons, rgb=rgb, border_pins=True)
+            if b > 0:
+                launches = solver.launches_for(b + 1)
+                if launches > 1 or (launches == 0 and b >= FILL_MIN):
+                    break                                   # this frame opens the next batch (its slot is re-set)
+            batch.append(ln)
+            j += 1
         solver.solve(len(batch), num_iter, non_linear_iter, linear_iter)
         solver.warp(len(batch))
-        for b, (ln, _) in enumerate(batch):
+        for b, ln in enumerate(batch):
             r = solver.results(b)
             Image.fromarray(r["warped_rgb"]).save(ln[4])
             save_mask(r["warped_mask"], ln[5])

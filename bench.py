@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8, help="frames solved concurrently per GPU per step")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames solved concurrently per GPU per step; 0 = 8, or with --multseg the count <= 16 that "
+                         "fills the resident launches best (probed with the frames of seeds 0, 1, ...)")
     ap.add_argument("--size", type=int, nargs=2, default=[854, 480], metavar=("W", "H"))
     ap.add_argument("--schedule", type=int, nargs=3, default=[19, 8, 400], metavar=("NUMITER", "NITER", "LITER"))
     ap.add_argument("--workload", choices=["davis", "full"], default="davis",
@@ -105,10 +107,26 @@ def main():
     from arap_flow_amd import opt, shard, synth
 
     W, H = a.size
-    B = a.batch
     numIter, nIter, lIter = a.schedule
     st = opt.State()
     K = max(1, a.multseg)
+    B = a.batch if a.batch > 0 else 8
+    if a.batch <= 0 and a.multseg:
+        # every solve gets a group of the resident launch's workgroups sized by its active tiles and a launch costs
+        # the same however full it is: take the frame count with the most frames per launch (same probe on every rank)
+        probe = opt.FrameSolver(st, W, H, batch=16 * K)
+        best, n = (0.0, 1), 0
+        for sd in range(16):
+            for sg in synth.segment_masks(synth.make_frame(W, H, seed=sd, K=K, fd=a.fd)):
+                probe.set_frame(n, sg["mask_red"], sg["constraints"])
+                n += 1
+            launches = probe.launches_for(n)
+            if launches <= 0:
+                break
+            if (sd + 1) / launches > best[0] + 1e-9:
+                best = ((sd + 1) / launches, sd + 1)             # most frames per launch, fewest frames on a tie
+        probe.close()
+        B = best[1]
     S = B * K                                    # solves per step on this rank
     fs = opt.FrameSolver(st, W, H, batch=S)
     # the job's frame list (world x B frames per step) is dealt round-robin to the ranks: no collective
@@ -211,7 +229,11 @@ def main():
             # HBM bytes per launch from rocprofv3 PMC passes (collected separately, profiles/)
             tf = os.path.join(ROOT, "profiles", "traffic_%s_b%d.json" % (a.workload, B))
             if os.path.exists(tf):
-                out["roofline"]["traffic"] = json.load(open(tf)).get(out["roofline"]["kernel"])
+                det = json.load(open(tf)).get(out["roofline"]["kernel"])
+                if det:
+                    out["roofline"]["traffic"] = det.get("hbm_bytes_per_launch")     # bytes per launch
+                    out["roofline"]["traffic_unit"] = "bytes per launch"
+                    out["roofline"]["traffic_detail"] = det
             out["resident_path"] = stats.get("resident_launches", 0) > 0
             # measured device copy bandwidth next to the nominal peak: 1 GiB float32 copy, read + write
             try:

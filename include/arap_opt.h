@@ -189,6 +189,14 @@ void ArapFlow_SetResident(Opt_State* state, int on);
  * when most tiles are active, direct otherwise).  Same arithmetic, identical results.  -1 for any other shape. */
 int ArapFlow_SetTile(Opt_State* state, int tile_x, int tile_y);
 uint64_t ArapFlow_SolverResidentLaunches(ArapFlow_Solver* s);
+/* How the last solve's frames were dealt to resident launches: launches per Gauss-Newton step and the largest
+ * number of solves in flight in one launch (every solve gets a group of the launch's 512 workgroups sized by its
+ * active-tile count; small solves share an XCD).  Both 0 when the two-kernel path ran.  Returns 0, -1 on NULL. */
+int ArapFlow_SolverResidentLayout(ArapFlow_Solver* s, int* launches_per_step, int* solves_in_flight);
+/* Resident launches per Gauss-Newton step that a solve of slots [0, nframes) would take with the frames set so far
+ * (0: the two-kernel path would run, -1: bad arguments).  Every launch costs about the same time however full it
+ * is, so a host that wants the best throughput adds frames to a batch while this stays 1 (arap_deform does). */
+int ArapFlow_SolverLaunchesFor(ArapFlow_Solver* s, unsigned nframes);
 /* The drop-in path (Opt_ProblemInit/Step/Solve) takes the resident kernel too when, at Init, the caller's
  * UrShape is the pixel grid on every active vertex (what the application passes, CombinedSolver.h:207-221) and
  * the active tiles fit; the Mask/UrShape buffers analysed at Init must then stay the ones passed to the Steps

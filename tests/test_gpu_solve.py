@@ -319,6 +319,39 @@ def test_solver_reuse_across_frames_of_different_tile_counts(gpu_state):
             one.close()
 
 
+def test_resident_packing_of_many_uneven_solves(gpu_state):
+    """The host deals every solve a group of the resident launch's 512 workgroups sized by its active-tile count and
+    packs small solves onto one XCD (arapopt.hip: plan_resident_pack).  48 solves of very different sizes need two
+    launches per step with more than 16 solves in flight; every one equals the two-kernel path bit for bit."""
+    from arap_flow_amd import synth
+    W, H = 256, 128                                             # 4 x 32 = 128 tiles of 64 x 4
+    solves = []
+    for s in range(36):                                         # whole-frame solves: 128 tiles = 15 workgroups each
+        solves.append(synth.make_frame(W, H, seed=100 + s, full_mask=True))
+    for s in range(4):                                          # and the three segments of four --multseg frames
+        solves += synth.segment_masks(synth.make_frame(W, H, seed=200 + s, K=3, fd=2))
+    n = len(solves)
+    sched = (1, 2, 30)
+    outs = []
+    for resident in (True, False):
+        gpu_state.set_resident(resident)
+        fs = opt.FrameSolver(gpu_state, W, H, batch=n)
+        for b, f in enumerate(solves):
+            fs.set_frame(b, f["mask_red"], f["constraints"])
+        fs.solve(n, *sched)
+        outs.append([fs.results(b, want_rgb=False) for b in range(n)])
+        st = fs.stats()
+        if resident:
+            assert st["resident_launches_per_step"] == 2 and st["resident_solves_in_flight"] > 16, st
+        else:
+            assert st["resident_launches_per_step"] == 0
+        fs.close()
+    gpu_state.set_resident(True)
+    for a, b in zip(*outs):
+        assert np.array_equal(a["offset"], b["offset"]) and np.array_equal(a["angle"], b["angle"])
+        assert a["cost"] == b["cost"]
+
+
 def test_frame_edge_cases_empty_mask_and_no_constraints(gpu_state, oracle):
     """a frame whose mask excludes every vertex (nothing to solve, flow stays 0), a frame without any file
     constraint (only the border pins act) and a batch mixing them with a normal frame"""
