@@ -99,11 +99,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    # one process per GPU.  (ARAP_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks:
+    # the ranks then share the visible GPUs and only the timing barrier / max-over-ranks change transport.)
+    backend = os.environ.get("ARAP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from arap_flow_amd import opt, shard, synth
 
     W, H = a.size
@@ -159,7 +167,7 @@ def main():
     ev_ms = st.timer_end()
     barrier()
     dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dist, device="cuda")
+    dt = shard.max_over_ranks(dt, dist, device="cuda" if backend == "nccl" else "cpu")
     stats = fs.stats()
     total_frames = world * B * a.steps
     fps = total_frames / dt
@@ -264,7 +272,7 @@ def main():
                                      "cpu": "oracle rasteriser, 1 thread (the reference's warp code is single threaded)"}
             except Exception as e:
                 out["warp_stage"] = {"error": str(e)[:200]}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:               # the CPU side is timed at N = 1 only
             out["cpu_baseline"] = cpu_baseline(frames[0], a.schedule)
         print(json.dumps(out))
     fs.close()

@@ -173,6 +173,28 @@ def test_bench_contract_json_line(tmp_path):
     assert c["kind"] == "port" and c["cores"] >= 1
 
 
+def test_bench_two_ranks_under_torch_distributed_run(tmp_path):
+    """The driver's N > 1 command line, rehearsed on one GPU: two ranks launched by torch.distributed.run share the
+    card (ARAP_BENCH_BACKEND=gloo moves only the timing barrier and the max-over-ranks off RCCL, which wants one GPU
+    per rank).  Rank 0 prints the one JSON line for the whole job; the CPU baseline is an N = 1 figure."""
+    import json
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ARAP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), osp.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--batch", "2", "--size", "214", "120", "--schedule", "2", "2", "30"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["frames_per_gpu_per_step"] == 2
+    assert abs(d["value"] - 2 * 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # all ranks' frames / max time
+    assert "roofline" in d and "cpu_baseline" not in d
+
+
 def test_resident_failure_falls_back_to_two_kernel_path(tmp_path):
     """ARAPOPT_FORCE_RES_FAIL=1 makes every resident launch report a timed-out group wait (what happens when the GPU
     is shared and the 512 workgroups are not co-resident).  The frame solver and the drop-in path must notice, redo the
