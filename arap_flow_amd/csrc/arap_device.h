@@ -61,6 +61,10 @@ struct PlanDev {
     // error word of the resident kernel (arap_resident.h), NULL when the plan has none: once it is set the step's
     // update is skipped so that the host can redo the step on the two-kernel path from unchanged unknowns
     const unsigned* res_err;
+    // resident path: k_gn_prep zeroes what the step's later kernels accumulate into or poll, instead of memset
+    // nodes: reduction slot 0 of every frame (rho_0, written by k_gn_init) and the granules of all launches
+    unsigned long long* res_gran;
+    int res_gran_n;          // u64 entries to zero; 0 = the two-kernel path (host memsets all slots of `red`)
 };
 
 // ---- cos/sin: same operation list as oracle/arap_oracle.c:arap_sincos_spec ----------------------

@@ -59,6 +59,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
     const int any = __syncthreads_or((int)(f & F_ACT));
     if (threadIdx.x == 0 && threadIdx.y == 0)
         pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
+    if (pd.res_gran_n) {
+        const int t = threadIdx.y * TILE_X + threadIdx.x;
+        if (v.wg == 0 && t < NSHARD) pd.red[(size_t)v.b * pd.nslots * NSHARD + t] = 0.0;
+        if (v.b == 0)
+            for (int i = (int)v.wg * (TILE_X * TILE_Y) + t; i < pd.res_gran_n; i += (int)(gridDim.x * gridDim.y) * (TILE_X * TILE_Y))
+                pd.res_gran[i] = 0ull;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -120,6 +120,9 @@ struct Opt_Plan {
     // resident PCG (arap_resident.h): only for the frame solver (pixel-grid UrShape, host-known masks)
     bool res_capable = false;       // device has 256 CUs and the kernel fits one workgroup per CU
     bool res_frames = false;        // plan is driven by ArapFlow_Solver
+    // ArapFlow_Solver reports one cost, the one after the last step of the last ramp iteration: the costs the
+    // reference evaluates at Init and after every step (for its log) are skipped unless cost_wanted
+    bool lazy_cost = false, cost_wanted = true;
     ResDev rd{};
     void* res_block = nullptr;
     std::vector<int> h_ntiles;
@@ -202,7 +205,7 @@ static void plan_enable_resident(Opt_Plan* p)
     }
     const size_t sz_tl = align_up((size_t)p->batch * RES_MAX_TILES * sizeof(int), 256);
     const size_t sz_nt = align_up((size_t)p->batch * sizeof(int), 256);
-    const size_t sz_gr = align_up((size_t)2 * RES_WGS * 2 * 8, 256);
+    const size_t sz_gr = align_up((size_t)p->batch * 2 * RES_WGS * 2 * 8, 256);   // one block per launch of a step
     const size_t sz_map = align_up((size_t)p->batch * RES_WGS * sizeof(ResWg), 256);
     HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map));
     HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map, st->stream));
@@ -541,17 +544,26 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
 {
     const int L = p->sp.lIterations;
     const dim3 g = p->grid(), b = p->blk();
-    // reduction slots 0 .. 2L of every active frame (contiguous because slot stride is nslots)
-    HC(hipMemsetAsync(p->pd.red, 0, (size_t)p->nb * p->pd.nslots * NSHARD * sizeof(double), s));
-    LAUNCH(p, s, "GNPrep", k_gn_prep, g, b, p->pd);
+    const bool res = plan_resident_eligible(p);
+    PlanDev pd = p->pd;
+    const size_t gran_per_launch = (size_t)2 * RES_WGS * 2;              // u64 entries
+    if (res) {
+        // k_gn_prep zeroes slot 0 of `red` (rho_0) and the granules of every launch of this step: no memset nodes.
+        // Granule tags restart at 1 in every launch (cdna guide G16 "re-initialise every call").
+        pd.res_gran = p->rd.gran;
+        pd.res_gran_n = (int)(gran_per_launch * p->res_sets);
+    } else {
+        // reduction slots 0 .. 2L of every active frame (contiguous because slot stride is nslots)
+        HC(hipMemsetAsync(p->pd.red, 0, (size_t)p->nb * p->pd.nslots * NSHARD * sizeof(double), s));
+    }
+    LAUNCH(p, s, "GNPrep", k_gn_prep, g, b, pd);
     LAUNCH(p, s, "PCGInit1", k_gn_init, g, b, p->pd);
-    if (plan_resident_eligible(p)) {
-        // all L iterations in one launch, state on chip (arap_resident.h).  Granule tags restart at 1
-        // in every launch, so the granule block is zeroed first (cdna guide G16 "re-initialise every call").
+    if (res) {
+        // all L iterations in one launch, state on chip (arap_resident.h)
         ResDev rd = p->rd;
         for (int set = 0; set < p->res_sets; ++set) {
             rd.wgmap = p->d_wgmap + (size_t)set * RES_WGS;
-            HC(hipMemsetAsync(rd.gran, 0, (size_t)2 * RES_WGS * 2 * 8, s));
+            rd.gran = p->rd.gran + gran_per_launch * set;
             if (rd.stamps)
                 hipLaunchKernelGGL(k_pcg_resident<true>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
             else
@@ -641,8 +653,9 @@ static void plan_init(Opt_Plan* p)
     plan_reserve(p, p->sp.lIterations, p->sp.nIterations + 1);
     plan_upload_slots(p);
     plan_analyse_for_resident(p);
+    if (p->lazy_cost && !p->cost_wanted && p->st->verbosity == 0) return;
     HC(hipMemsetAsync(p->pd.costred, 0, (size_t)p->nb * p->pd.ncost * NSHARD * sizeof(double), p->st->stream));
-    plan_cost(p, 0);
+    if (!p->lazy_cost || p->st->verbosity > 0 || p->sp.nIterations == 0) plan_cost(p, 0);
 }
 
 // step: solverGPUGaussNewton.t:1016-1177 (GN branch)
@@ -657,7 +670,8 @@ static int plan_step(Opt_Plan* p)
             HC(hipStreamSynchronize(p->st->stream));
             if (plan_resident_failed(p)) plan_gn_step(p);          // X untouched: redo on the two-kernel path
         }
-        plan_cost(p, p->sp.nIter + 1);
+        if (!p->lazy_cost || p->st->verbosity > 0 || (p->cost_wanted && p->sp.nIter + 1 == p->sp.nIterations))
+            plan_cost(p, p->sp.nIter + 1);
         if (p->st->verbosity > 0) {
             const double a = plan_read_cost(p, 0, p->sp.nIter), b = plan_read_cost(p, 0, p->sp.nIter + 1);
             printf("cost: %f -> %f\n", a, b);
@@ -1276,6 +1290,8 @@ int ArapFlow_SolverSolve(ArapFlow_Solver* s, unsigned nframes, unsigned numIter,
         for (unsigned i = 0; i < numIter; ++i) {
             const float alpha = (float)(i + 1) / (float)numIter;          // CombinedSolver.h:199-201
             hipLaunchKernelGGL(k_frame_ramp, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N, alpha);
+            p->lazy_cost = true;
+            p->cost_wanted = i + 1 == numIter;
             plan_init(p);
             while (plan_step(p) != 0) {}
         }
