@@ -101,6 +101,12 @@ __device__ __forceinline__ float2 fma2(float2 a, float2 b, float2 c)
     const v2f_t r = __builtin_elementwise_fma((v2f_t){a.x, a.y}, (v2f_t){b.x, b.y}, (v2f_t){c.x, c.y});
     return make_float2(r.x, r.y);
 }
+// v if bit `BITNO` of f is set, else +0: v_bfe_i32 (0 / all ones) + v_and_b32, no lane mask in SGPRs
+template <int BITNO>
+__device__ __forceinline__ float keep_if(unsigned f, float v)
+{
+    return __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe((int)f, BITNO, 1));
+}
 __device__ __forceinline__ float2 ld_sc1_f2(const float2* p)
 {
     const unsigned long long u =
@@ -243,6 +249,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         if (tid == 0) *nhalo = 0;
     }
 
+    // every cell of the halo'd tiles holds a finite value: cells outside the image or of unused slots are never
+    // written below, and phase A multiplies (not selects) the contributions of invalid edges by zero
+    for (int c = tid; c < RES_TILES_PER_WG * LTILE; c += RES_THREADS) lds[c] = 0.f;
+    __syncthreads();
+
     float rx[RES_SLOTS], ry[RES_SLOTS], ra[RES_SLOTS];
     float dx_[RES_SLOTS], dy_[RES_SLOTS], da_[RES_SLOTS];
     float apx[RES_SLOTS], apy[RES_SLOTS], apa[RES_SLOTS];
@@ -350,24 +361,42 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
     for (int l = 0; l < L && alive; ++l) {
         // ---------------- phase A: Ap = J^T J p, sigma = p.Ap --------------------------------------
+        // Software pipelined over the tile slots: the 15 LDS reads of slot j+1 (own cell + 4 neighbours x
+        // {(px,py), (cos,sin), pa}) are issued before the arithmetic of slot j, so that with only two wavefronts
+        // per SIMD the LDS round trip hides behind ~70 VALU instructions instead of stalling every slot.
+        static_assert(F_E0 == 1u && F_E1 == 2u && F_E2 == 4u && F_E3 == 8u && F_FIT == 16u && F_ACT == 32u, "bit numbers below");
         double acc = 0.0;
+        float2 Lpv[2], Lcs[2], LqO[2][4], Lcn[2][4];
+        float Lpa[2], LqA[2][4];
+#define RES_LOAD(J)                                                                                    \
+        {                                                                                              \
+            const int s_ = (J) & 1;                                                                    \
+            const float* T_ = lds + (J) * LTILE;                                                       \
+            Lpv[s_] = TP2(T_)[cell]; Lcs[s_] = TCS(T_)[cell]; Lpa[s_] = TPA(T_)[cell];                 \
+            LqO[s_][0] = TP2(T_)[cell + 1]; Lcn[s_][0] = TCS(T_)[cell + 1]; LqA[s_][0] = TPA(T_)[cell + 1];             \
+            LqO[s_][1] = TP2(T_)[cell - 1]; Lcn[s_][1] = TCS(T_)[cell - 1]; LqA[s_][1] = TPA(T_)[cell - 1];             \
+            LqO[s_][2] = TP2(T_)[cell + LROW]; Lcn[s_][2] = TCS(T_)[cell + LROW]; LqA[s_][2] = TPA(T_)[cell + LROW];    \
+            LqO[s_][3] = TP2(T_)[cell - LROW]; Lcn[s_][3] = TCS(T_)[cell - LROW]; LqA[s_][3] = TPA(T_)[cell - LROW];    \
+        }
+        RES_LOAD(0)
 #pragma unroll
         for (int j = 0; j < RES_SLOTS; ++j) {
-            const int k = j;
-            const unsigned f = fl[j];
+            unsigned f = fl[j];
+            // keep the flag tests inside the loop: hoisted, their 54 lane masks spill out of the SGPR file and
+            // come back as two v_readlane per test, more than the two bit operations that make a weight here
+            asm volatile("" : "+v"(f));
+            const int sj = j & 1;
+            if (j + 1 < RES_SLOTS) RES_LOAD(j + 1)
+            __builtin_amdgcn_sched_barrier(0);
             {
-                // Branch free: every lane evaluates all four edges (LDS reads stay inside the halo'd tile) and
-                // keeps a contribution only where its flag bit is set, so the slots form one basic block and the
-                // scheduler can overlap one slot's LDS latency with another slot's arithmetic.  Selecting (not
-                // multiplying by 0) keeps NaNs of never-written halo cells out.  (Edge weights wr2/0 instead of
-                // selects were tried: hoisted out of the loop they cost 45 VGPRs and spill, recomputed per
-                // iteration they cost as many instructions as the selects.)
-                const float* T = lds + k * LTILE;
-                const float2 pv = TP2(T)[cell];
-                const float2 csv = TCS(T)[cell];                 // (ci, si)
-                const float pa_ = TPA(T)[cell];
+                // Branch free: every lane evaluates all four edges (LDS reads stay inside the halo'd tile, whose
+                // never-written cells were zero-filled in the prologue, so every operand is finite) and an edge
+                // whose flag bit is clear gets the weight +0: fma(0, u, a) = a exactly.
+                const float2 pv = Lpv[sj];
+                const float2 csv = Lcs[sj];                      // (ci, si)
+                const float pa_ = Lpa[sj];
                 const float ci = csv.x, si = csv.y;
-                const float2 pa2 = make_float2(pa_, pa_), w2 = make_float2(wr2, wr2);
+                const float2 pa2 = make_float2(pa_, pa_);
                 float2 axy = make_float2(0.f, 0.f);
                 float aa = 0.f;
                 // On the pixel grid d = U(c)-U(n) = -s, so q = R'(A(c))d and h = R'(A(n))d are signed copies of
@@ -375,39 +404,36 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 // block is the generic k_pcg_a expression
                 //   t = fma(-q, pa, dP) ; a_xy = fma(wr2, fma(-h, qA, dP + t), a_xy) ; aa = fma(-wr2, fma(qx,tx,qy ty), aa)
                 // on (x,y) pairs (v_pk_fma_f32), value for value (only the sign of an exact zero may differ).
-#define RES_EDGE(BIT, NC, NQX, NQY, NHX, NHY, QX, QY)                                                  \
+#define RES_EDGE(BITNO, E, NQX, NQY, NHX, NHY, QX, QY)                                                 \
                 {                                                                                      \
-                    const int nc = (NC);                                                               \
-                    const float2 qO = TP2(T)[nc], cn2 = TCS(T)[nc];                                    \
-                    const float qA = TPA(T)[nc];                                                       \
+                    const float2 qO = LqO[sj][E], cn2 = Lcn[sj][E];                                    \
+                    const float qA = LqA[sj][E];                                                       \
                     const float cn = cn2.x, sn = cn2.y;                                                \
+                    const float w = keep_if<BITNO>(f, wr2);                                            \
                     const float2 e = pv - qO;                                                          \
                     const float2 t = fma2(make_float2(NQX, NQY), pa2, e);                              \
                     const float2 u = fma2(make_float2(NHX, NHY), make_float2(qA, qA), e + t);          \
-                    const float2 nax = fma2(w2, u, axy);                                               \
-                    const float naa = fmaf(-wr2, fmaf(QX, t.x, (QY) * t.y), aa);                       \
-                    const bool on = (f & (BIT)) != 0;                                                  \
-                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y; aa = on ? naa : aa;        \
+                    axy = fma2(make_float2(w, w), u, axy);                                             \
+                    aa = fmaf(-w, fmaf(QX, t.x, (QY) * t.y), aa);                                      \
                     (void)cn; (void)sn;                                                                \
                 }
-                //        bit   neighbour     -q          -h          q
-                RES_EDGE(F_E0, cell + 1,     -si,  ci,   -sn,  cn,    si, -ci)      // s=( 1, 0): q=( si,-ci) h=( sn,-cn)
-                RES_EDGE(F_E1, cell - 1,      si, -ci,    sn, -cn,   -si,  ci)      // s=(-1, 0): q=(-si, ci) h=(-sn, cn)
-                RES_EDGE(F_E2, cell + LROW,  -ci, -si,   -cn, -sn,    ci,  si)      // s=( 0, 1): q=( ci, si) h=( cn, sn)
-                RES_EDGE(F_E3, cell - LROW,   ci,  si,    cn,  sn,   -ci, -si)      // s=( 0,-1): q=(-ci,-si) h=(-cn,-sn)
+                //     bit no edge    -q          -h          q
+                RES_EDGE(0, 0,     -si,  ci,   -sn,  cn,    si, -ci)      // s=( 1, 0): q=( si,-ci) h=( sn,-cn)
+                RES_EDGE(1, 1,      si, -ci,    sn, -cn,   -si,  ci)      // s=(-1, 0): q=(-si, ci) h=(-sn, cn)
+                RES_EDGE(2, 2,     -ci, -si,   -cn, -sn,    ci,  si)      // s=( 0, 1): q=( ci, si) h=( cn, sn)
+                RES_EDGE(3, 3,      ci,  si,    cn,  sn,   -ci, -si)      // s=( 0,-1): q=(-ci,-si) h=(-cn,-sn)
 #undef RES_EDGE
                 {
-                    const float2 nax = fma2(make_float2(wf2, wf2), pv, axy);
-                    const bool on = (f & F_FIT) != 0;
-                    axy.x = on ? nax.x : axy.x; axy.y = on ? nax.y : axy.y;
+                    const float wf = keep_if<4>(f, wf2);
+                    axy = fma2(make_float2(wf, wf), pv, axy);
                 }
                 const float ax = axy.x, ay = axy.y;
                 apx[j] = ax; apy[j] = ay; apa[j] = aa;
-                const float dt = dot3(pv.x, pv.y, pa_, ax, ay, aa);
-                acc += (f & F_ACT) ? (double)dt : 0.0;
+                acc += (double)keep_if<5>(f, dot3(pv.x, pv.y, pa_, ax, ay, aa));
             }
-            if (RES_PAIR_SLOTS == 1 || (j % RES_PAIR_SLOTS) == RES_PAIR_SLOTS - 1) __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef RES_LOAD
         float sigma;
         RES_STAMP(tA);
         alive = group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast);

@@ -27,3 +27,10 @@ print("workgroups active", used.sum(), "tiles/WG", o[used, 5].min(), o[used, 5].
 for n, col in zip(["phaseA", "wait1", "phaseB+drain", "wait2", "update"], us.T):
     print("%-14s mean %.2f  min %.2f  max %.2f us" % (n, col.mean(), col.min(), col.max()))
 print("sum of means %.2f us" % us.mean(0).sum())
+# per-workgroup view of one group (the workgroups of XCD 0: blockIdx & 7 == 0), sorted by tiles then phase A time
+idx = np.arange(512)
+g0 = used & ((idx & 7) == 0)
+rows = sorted(zip(o[g0, 5], o[g0, 6], *(o[g0, c] * 0.01 / L for c in range(5)), idx[g0] >> 3), key=lambda r: (r[0], r[2]))
+print("XCD 0 workgroups: tiles halo | phaseA wait1 phaseB wait2 update | local index")
+for r in rows:
+    print("%3d %5d | %5.2f %5.2f %5.2f %5.2f %5.2f | %2d" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]))
