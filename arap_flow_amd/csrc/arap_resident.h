@@ -105,7 +105,9 @@ __device__ __forceinline__ float2 fma2(float2 a, float2 b, float2 c)
 template <int BITNO>
 __device__ __forceinline__ float keep_if(unsigned f, float v)
 {
-    return __uint_as_float(__float_as_uint(v) & (unsigned)__builtin_amdgcn_sbfe((int)f, BITNO, 1));
+    int m;      // (as asm: the compiler would turn sext(bit) & v back into v_and + v_cmp + v_cndmask)
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(f), "n"(BITNO));
+    return __uint_as_float(__float_as_uint(v) & (unsigned)m);
 }
 __device__ __forceinline__ float2 ld_sc1_f2(const float2* p)
 {
@@ -343,6 +345,18 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
     }
 
+    // byte offsets of this lane's cell and its four neighbours inside a tile's float2 planes / float plane
+    unsigned offP[5], offA[5];
+    {
+        const int dn[5] = {0, 1, -1, LROW, -LROW};
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            offP[n] = (unsigned)(cell + dn[n]) * 8u;
+            offA[n] = (unsigned)(cell + dn[n]) * 4u;
+            asm volatile("" : "+v"(offP[n]));
+            asm volatile("" : "+v"(offA[n]));
+        }
+    }
     bool alive = true;
     // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------
     // every workgroup publishes xcc + 65536 xcc^2 through the placement-independent protocol (epoch 1);
@@ -368,15 +382,21 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         double acc = 0.0;
         float2 Lpv[2], Lcs[2], LqO[2][4], Lcn[2][4];
         float Lpa[2], LqA[2][4];
+        // Every read has its own opaque base (cell, +1, -1, +row, -row; float2 and float planes) plus an immediate
+        // offset: that keeps them single ds_read_b64 / ds_read_b32 (2 LDS cycles per wave instruction); merged into
+        // ds_read2_b64 by the compiler they take 8 cycles per pair (MI355X_MICROARCH.md, LDS table).
 #define RES_LOAD(J)                                                                                    \
         {                                                                                              \
             const int s_ = (J) & 1;                                                                    \
-            const float* T_ = lds + (J) * LTILE;                                                       \
-            Lpv[s_] = TP2(T_)[cell]; Lcs[s_] = TCS(T_)[cell]; Lpa[s_] = TPA(T_)[cell];                 \
-            LqO[s_][0] = TP2(T_)[cell + 1]; Lcn[s_][0] = TCS(T_)[cell + 1]; LqA[s_][0] = TPA(T_)[cell + 1];             \
-            LqO[s_][1] = TP2(T_)[cell - 1]; Lcn[s_][1] = TCS(T_)[cell - 1]; LqA[s_][1] = TPA(T_)[cell - 1];             \
-            LqO[s_][2] = TP2(T_)[cell + LROW]; Lcn[s_][2] = TCS(T_)[cell + LROW]; LqA[s_][2] = TPA(T_)[cell + LROW];    \
-            LqO[s_][3] = TP2(T_)[cell - LROW]; Lcn[s_][3] = TCS(T_)[cell - LROW]; LqA[s_][3] = TPA(T_)[cell - LROW];    \
+            const char* T_ = (const char*)lds + (J) * (LTILE * 4);                                     \
+            Lpv[s_] = *(const float2*)(T_ + offP[0]);                                                  \
+            Lcs[s_] = *(const float2*)(T_ + offP[0] + LPLANE * 8);                                     \
+            Lpa[s_] = *(const float*)(T_ + offA[0] + LPLANE * 16);                                     \
+            _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_) {                                         \
+                LqO[s_][n_] = *(const float2*)(T_ + offP[n_ + 1]);                                     \
+                Lcn[s_][n_] = *(const float2*)(T_ + offP[n_ + 1] + LPLANE * 8);                        \
+                LqA[s_][n_] = *(const float*)(T_ + offA[n_ + 1] + LPLANE * 16);                        \
+            }                                                                                          \
         }
         RES_LOAD(0)
 #pragma unroll
