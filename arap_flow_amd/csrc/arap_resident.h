@@ -43,8 +43,9 @@ constexpr int LROWS = TILE_Y + 2;        // 6
 constexpr int LPLANE = LROW * LROWS;     // 396 floats
 constexpr int LTILE = 5 * LPLANE;        // float2 (px,py) plane | float2 (cos,sin) plane | float pa plane
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
-                              + ((RES_MAX_HALO * 2 + 15) / 16) * 16   // halo list
-                              + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (~74 KB: 2 per CU)
+                              + ((RES_MAX_HALO * 8 + 15) / 16) * 16   // halo list (u16), then the decoded halo table (uint2)
+                              + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (79.6 KB: 2 per CU)
+static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two workgroups per CU");
 #ifndef RES_PAIR_SLOTS
 #define RES_PAIR_SLOTS 1      // slots of phase A the scheduler may interleave (register pressure vs latency hiding)
 #endif
@@ -175,9 +176,13 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
 }
 
 // block-wide sum of a double over the 4 wavefronts; result valid in wave 0 lane 0
+template <bool DRAIN = false>
 __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 doubles */)
 {
     v = wave_sum(v);
+    // DRAIN: the wave's earlier global stores must have landed before the workgroup barrier below (R1); waiting
+    // here, after the shuffles, hides part of the store latency
+    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) wsum[wave] = v;
     __syncthreads();
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wy = wave;                               // row inside the tile
     unsigned short* hlist = (unsigned short*)(lds + RES_TILES_PER_WG * LTILE);    // [RES_MAX_HALO]
-    int2* tbase = (int2*)((char*)hlist + ((RES_MAX_HALO * 2 + 15) / 16) * 16);    // [9] tile origin (x0, y0)
+    int2* tbase = (int2*)((char*)hlist + ((RES_MAX_HALO * 8 + 15) / 16) * 16);    // [9] tile origin (x0, y0)
     float* moLUT = (float*)(tbase + RES_TILES_PER_WG + 1);                // [10] (+2 pad)
     float* bcast = moLUT + 12;                                            // 2 floats + nhalo (int) + pad
     int* nhalo = (int*)(bcast + 2);
@@ -261,6 +266,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     float apx[RES_SLOTS], apy[RES_SLOTS], apa[RES_SLOTS];
     float ma_[RES_SLOTS], mo_[RES_SLOTS];
     unsigned fl[RES_SLOTS];
+    int ibase[RES_SLOTS];                              // SGPRs
+    const int loff = lane + W * wy;                    // this lane's vertex inside a tile: index = ibase + loff
 
     // LDS tile t: float2 P2[396] (px,py) | float2 CS[396] (cos,sin) | float PA[396]; cell = row*66 + col
     const int cell = (wy + 1) * LROW + (lane + 1);
@@ -286,11 +293,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             float* T = lds + k * LTILE;
             if (x < W && y < H) {
                 const int i = x + W * y;
+                // Only ACTIVE vertices enter LDS; every other cell keeps the zero written above (k_gn_init leaves
+                // p0 of excluded vertices untouched and their cos/sin come from whatever Angle the caller holds:
+                // phase A multiplies such neighbours by a zero weight, so they must be finite).
                 f = pd.flags[gb + i];
-                TP2(T)[cell] = pd.pO0[gb + i];
-                TCS(T)[cell] = pd.cs[gb + i];
-                TPA(T)[cell] = pd.pA0[gb + i];
                 if (f & F_ACT) {
+                    TP2(T)[cell] = pd.pO0[gb + i];
+                    TCS(T)[cell] = pd.cs[gb + i];
+                    TPA(T)[cell] = pd.pA0[gb + i];
                     const float2 r = pd.rO[gb + i];
                     rx[j] = r.x; ry[j] = r.y; ra[j] = pd.rA[gb + i];
                     mA = pd.preA[gb + i];
@@ -299,19 +309,20 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 int hi = -1, hc = 0;
                 if (wy == 0 && y0 > 0) { hi = i - W; hc = 0 * LROW + (lane + 1); }
                 if (wy == 3 && y + 1 < H) { hi = i + W; hc = 5 * LROW + (lane + 1); }
-                if (hi >= 0) {
+                if (hi >= 0 && (pd.flags[gb + hi] & F_ACT)) {
                     TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
                 }
                 hi = -1;
                 if (lane == 0 && x0 > 0) { hi = i - 1; hc = (wy + 1) * LROW + 0; }
                 if (lane == 63 && x + 1 < W) { hi = i + 1; hc = (wy + 1) * LROW + 65; }
-                if (hi >= 0) {
+                if (hi >= 0 && (pd.flags[gb + hi] & F_ACT)) {
                     TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
                 }
             }
         }
         fl[j] = f;
         ma_[j] = mA;
+        ibase[j] = __builtin_amdgcn_readfirstlane(x0 + W * y0);        // uniform: vertex index of the tile origin
         if (tid == 0) tbase[k] = make_int2(x0, y0);
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -329,21 +340,31 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     __syncthreads();
     const int nh = *nhalo;
-    // this lane's share of the halo list, decoded once: LDS cell (tile * LTILE + cell) and global vertex index
-    int hcell[RES_HALO_PER_THREAD], hgi[RES_HALO_PER_THREAD];
+    // this lane's share of the halo list, decoded once into an LDS table (the u16 list is dead after decoding and
+    // registers are needed elsewhere): entry c = tid + u * 256 holds {global vertex index of the halo cell,
+    // (byte offset in the float2 planes) / 8 | (byte offset in the float plane) / 4 << 16}
+    uint2* htab = (uint2*)hlist;                                          // [RES_MAX_HALO]
+    {
+        uint2 e[RES_HALO_PER_THREAD];
 #pragma unroll
-    for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
-        const int c = tid + u * RES_THREADS;
-        hcell[u] = -1; hgi[u] = 0;
-        if (c < nh) {
-            const int id = hlist[c];
-            const int k = id / LPLANE, rem = id - k * LPLANE;
-            const int row = rem / LROW, col = rem - row * LROW;
-            const int2 tb = tbase[k];
-            hgi[u] = (tb.x + col - 1) + W * (tb.y + row - 1);
-            hcell[u] = k * LTILE + rem;              // float2 index of the P2 plane; PA plane = lds + k*LTILE + 4*LPLANE + rem
+        for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
+            const int c = tid + u * RES_THREADS;
+            e[u] = make_uint2(0u, 0u);
+            if (c < nh) {
+                const int id = hlist[c];
+                const int k = id / LPLANE, rem = id - k * LPLANE;
+                const int row = rem / LROW, col = rem - row * LROW;
+                const int2 tb = tbase[k];
+                e[u].x = (unsigned)((tb.x + col - 1) + W * (tb.y + row - 1));
+                e[u].y = (unsigned)(k * (LTILE / 2) + rem) | ((unsigned)(k * LTILE + 4 * LPLANE + rem) << 16);
+            }
         }
+        __syncthreads();                             // every u16 entry has been read
+#pragma unroll
+        for (int u = 0; u < RES_HALO_PER_THREAD; ++u) htab[tid + u * RES_THREADS] = e[u];
+        // (each thread reads back only what it wrote: no barrier needed)
     }
+    static_assert(RES_TILES_PER_WG * LTILE < 65536 && LTILE % 2 == 0, "halo table packs 16-bit cell offsets");
 
     // byte offsets of this lane's cell and its four neighbours inside a tile's float2 planes / float plane
     unsigned offP[5], offA[5];
@@ -357,6 +378,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             asm volatile("" : "+v"(offA[n]));
         }
     }
+    float2* const zO_b = pd.zO + gb;                   // this frame's published z (uniform bases)
+    float* const zA_b = pd.zA + gb;
     bool alive = true;
     // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------
     // every workgroup publishes xcc + 65536 xcc^2 through the placement-independent protocol (epoch 1);
@@ -459,38 +482,53 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         alive = group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast);
         if (!alive) break;
         RES_STAMP(tS1);
-        // ---------------- phase B: alpha, delta, r, z, rho' -----------------------------------------
+        // ---------------- phase B: alpha, r, z, rho', delta ---------------------------------------------
+        // Branch free except for the stores: an excluded lane has r = Ap = 0 and M^-1_A = 0, so its r, z stay 0.
         float alpha = 0.f;
         if (sigma > 0.f) alpha = rho / sigma;
         acc = 0.0;
 #pragma unroll
         for (int j = 0; j < RES_SLOTS; ++j) {
-            const int k = j;
-            const unsigned f = fl[j];
+            unsigned f = fl[j];
+            asm volatile("" : "+v"(f));
+            const float mo = mo_[j], ma = ma_[j];
+            rx[j] = fmaf(-alpha, apx[j], rx[j]);
+            ry[j] = fmaf(-alpha, apy[j], ry[j]);
+            ra[j] = fmaf(-alpha, apa[j], ra[j]);
+            const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
             if (f & F_ACT) {
-                const float* T = lds + k * LTILE;
-                const float2 pv = TP2(T)[cell];
-                const float pa_ = TPA(T)[cell];
-                const float mo = mo_[j], ma = ma_[j];
-                const int2 tb = tbase[k];
-                const int i = tb.x + lane + W * (tb.y + wy);
-                dx_[j] = fmaf(alpha, pv.x, dx_[j]);
-                dy_[j] = fmaf(alpha, pv.y, dy_[j]);
-                da_[j] = fmaf(alpha, pa_, da_[j]);
-                rx[j] = fmaf(-alpha, apx[j], rx[j]);
-                ry[j] = fmaf(-alpha, apy[j], ry[j]);
-                ra[j] = fmaf(-alpha, apa[j], ra[j]);
-                const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-                st_pub_f2(pd.zO + gb + i, make_float2(zx, zy), fast);      // (publishing border vertices only was
-                st_pub_f(pd.zA + gb + i, za, fast);                         //  measured slower: divergent stores)
-                acc += (double)dot3(zx, zy, za, rx[j], ry[j], ra[j]);
+                const unsigned i = (unsigned)(ibase[j] + loff);
+                st_pub_f2((float2*)((char*)zO_b + (size_t)(i * 8u)), make_float2(zx, zy), fast);   // (publishing border
+                st_pub_f((float*)((char*)zA_b + (size_t)(i * 4u)), za, fast);   // vertices only: slower, divergent stores)
             }
+            acc += (double)keep_if<5>(f, dot3(zx, zy, za, rx[j], ry[j], ra[j]));
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains (R1)
+        // delta += alpha p while the z stores travel (own p from LDS, reads one slot ahead)
+        {
+            float2 Dp[2];
+            float Da[2];
+#define RES_LOADP(J, P2_, PA_)                                                                         \
+            {                                                                                          \
+                const char* T_ = (const char*)lds + (J) * (LTILE * 4);                                 \
+                P2_[(J) & 1] = *(const float2*)(T_ + offP[0]);                                         \
+                PA_[(J) & 1] = *(const float*)(T_ + offA[0] + LPLANE * 16);                            \
+            }
+            RES_LOADP(0, Dp, Da)
+#pragma unroll
+            for (int j = 0; j < RES_SLOTS; ++j) {
+                if (j + 1 < RES_SLOTS) RES_LOADP(j + 1, Dp, Da)
+                __builtin_amdgcn_sched_barrier(0);
+                dx_[j] = fmaf(alpha, Dp[j & 1].x, dx_[j]);
+                dy_[j] = fmaf(alpha, Dp[j & 1].y, dy_[j]);
+                da_[j] = fmaf(alpha, Da[j & 1], da_[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         float rhoNew;
         RES_STAMP(tB);
-        alive = group_sum(block_sum8(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast);
+        // (every storing wave drains inside block_sum8, before the workgroup barrier: R1)
+        alive = group_sum(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast);
         if (!alive) break;
         RES_STAMP(tS2);
         float beta = 0.f;
@@ -505,34 +543,42 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
             hz2[u] = make_float2(0.f, 0.f);
             hz1[u] = 0.f;
-            if (hcell[u] >= 0) {
-                hz2[u] = ld_sc1_f2(pd.zO + gb + hgi[u]);
-                hz1[u] = ld_sc1_f(pd.zA + gb + hgi[u]);
+            if (tid + u * RES_THREADS < nh) {
+                // uniform base + 32-bit byte offset formed here (precomputed 64-bit addresses would spill)
+                const unsigned gi = htab[tid + u * RES_THREADS].x;
+                hz2[u] = ld_sc1_f2((const float2*)((const char*)zO_b + (size_t)(gi * 8u)));
+                hz1[u] = ld_sc1_f((const float*)((const char*)zA_b + (size_t)(gi * 4u)));
             }
         }
-        // (2) own cells while those loads fly
+        // (2) own cells while those loads fly: branch free (an excluded lane computes 0 + beta * 0), LDS reads one
+        //     slot ahead of the writes
+        {
+            float2 Up[2];
+            float Ua[2];
+            RES_LOADP(0, Up, Ua)
 #pragma unroll
-        for (int j = 0; j < RES_SLOTS; ++j) {
-            const int k = j;
-            const unsigned f = fl[j];
-            if (f & F_ACT) {
-                float* T = lds + k * LTILE;
+            for (int j = 0; j < RES_SLOTS; ++j) {
+                if (j + 1 < RES_SLOTS) RES_LOADP(j + 1, Up, Ua)
+                __builtin_amdgcn_sched_barrier(0);
+                char* T_ = (char*)lds + j * (LTILE * 4);
                 const float mo = mo_[j], ma = ma_[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-                const float2 po = TP2(T)[cell];
-                TP2(T)[cell] = make_float2(fmaf(beta, po.x, zx), fmaf(beta, po.y, zy));
-                TPA(T)[cell] = fmaf(beta, TPA(T)[cell], za);
+                *(float2*)(T_ + offP[0]) = make_float2(fmaf(beta, Up[j & 1].x, zx), fmaf(beta, Up[j & 1].y, zy));
+                *(float*)(T_ + offA[0] + LPLANE * 16) = fmaf(beta, Ua[j & 1], za);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#undef RES_LOADP
         }
         // (3) halo cells: p_halo = z_halo + beta p_halo (the owner computes the same expression)
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
-            if (hcell[u] >= 0) {
-                const int k = hcell[u] / LTILE, rem = hcell[u] - k * LTILE;
-                float* T = lds + k * LTILE;
-                const float2 po = TP2(T)[rem];
-                TP2(T)[rem] = make_float2(fmaf(beta, po.x, hz2[u].x), fmaf(beta, po.y, hz2[u].y));
-                TPA(T)[rem] = fmaf(beta, TPA(T)[rem], hz1[u]);
+            if (tid + u * RES_THREADS < nh) {
+                const unsigned pk = htab[tid + u * RES_THREADS].y;
+                float2* P = (float2*)((char*)lds + (pk & 0xffffu) * 8u);
+                float* A = (float*)((char*)lds + (pk >> 16) * 4u);
+                const float2 po = *P;
+                *P = make_float2(fmaf(beta, po.x, hz2[u].x), fmaf(beta, po.y, hz2[u].y));
+                *A = fmaf(beta, *A, hz1[u]);
             }
         }
         __syncthreads();
@@ -544,13 +590,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     if (!alive) return;
     // ---- epilogue: delta back to the plan images for k_gn_update --------------------------------------
+    int lo = loff;
+    asm volatile("" : "+v"(lo));       // (else the nine store addresses are formed before the loop and spilled)
 #pragma unroll
     for (int j = 0; j < RES_SLOTS; ++j) {
-        const int k = j;
         const unsigned f = fl[j];
         if (f & F_ACT) {
-            const int2 tb = tbase[k];
-            const int i = tb.x + lane + W * (tb.y + wy);
+            const int i = ibase[j] + lo;
             pd.deltaO[gb + i] = make_float2(dx_[j], dy_[j]);
             pd.deltaA[gb + i] = da_[j];
         }
