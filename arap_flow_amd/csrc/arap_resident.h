@@ -121,10 +121,32 @@ __device__ __forceinline__ float ld_sc1_f(const float* p)
     return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// Sum of a double over the 64 lanes with DPP row shifts / broadcasts (the order LLVM's wave scan uses on gfx9:
+// row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2-3).
+// The total is valid in LANE 63.  A __shfl tree costs six dependent ds_bpermute round trips (~0.3 us) per sum, and
+// an iteration has four sums on its critical path.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);             // lanes without a source add +0.0
+}
+__device__ __forceinline__ double wave_sum_l63(double v)
+{
+    v = dpp_add_f64<0x111, 0xf>(v);                  // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);                  // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);                  // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);                  // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add_f64<0x142, 0xa>(v);                  // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc>(v);                  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+
 // Group-wide sum of one double per workgroup.  `part` is this workgroup's partial (valid in wave 0,
 // lane 0).  Wave 0 publishes it as two {tag, 32 bits} granules and sweeps the group's granules until
 // every tag equals `epoch`; lane k owns workgroups k, k+64, ... and adds their partials in that order,
-// then a fixed xor-butterfly adds the lanes, so every workgroup of the group computes the same bits.
+// then the fixed DPP tree above adds the lanes, so every workgroup of the group computes the same bits.
 // Returns the sum rounded to float in every thread; false on timeout.
 __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned long long* gran_group, int rank,
                                           int wgs, float* bcast /* LDS, 2 floats */, unsigned* err, float& out,
@@ -159,9 +181,8 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
             if (ok) break;
             __builtin_amdgcn_s_sleep(1);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) {
+        v = wave_sum_l63(v);
+        if (lane == 63) {
             bcast[0] = (float)v;
             if (out_d) *out_d = v;         // LDS double, read by the caller after the barrier below
             bcast[1] = ok ? 1.0f : 0.0f;
@@ -179,12 +200,12 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
 template <bool DRAIN = false>
 __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 doubles */)
 {
-    v = wave_sum(v);
+    v = wave_sum_l63(v);
     // DRAIN: the wave's earlier global stores must have landed before the workgroup barrier below (R1); waiting
-    // here, after the shuffles, hides part of the store latency
+    // here, after the lane sum, hides part of the store latency
     if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) wsum[wave] = v;
+    if (lane == 63) wsum[wave] = v;
     __syncthreads();
     double t = 0.0;
     if (wave == 0 && lane == 0) {
