@@ -155,7 +155,9 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
         unsigned long long* buf = gran_group + (size_t)(epoch & 1u) * wgs * 2;
-        part = __shfl(part, 0, 64);
+        // lane 0 holds the partial: v_readfirstlane (a __shfl would be two ds_bpermute round trips)
+        part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
+                                __builtin_amdgcn_readfirstlane(__double2loint(part)));
         if (lane < 2) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(part);
             const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
@@ -183,17 +185,18 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
         }
         v = wave_sum_l63(v);
         if (lane == 63) {
-            bcast[0] = (float)v;
+            // value with the sign bit of the second word as the "timed out" flag (one ds_write_b64); the slot
+            // alternates with the epoch, so the next call's write cannot overtake a slow reader of this one
+            // (before wave 0 writes slot p again, every wave has passed the barrier of the call in between)
+            *(float2*)(bcast + 2 * (epoch & 1u)) = make_float2((float)v, ok ? 1.0f : 0.0f);
             if (out_d) *out_d = v;         // LDS double, read by the caller after the barrier below
-            bcast[1] = ok ? 1.0f : 0.0f;
             if (!ok) atomicExch(err, 0xDEAD0000u | (epoch & 0xffffu));
         }
     }
     __syncthreads();
-    out = bcast[0];
-    const bool good = bcast[1] != 0.0f;
-    __syncthreads();      // bcast may be rewritten by the next call
-    return good;
+    const float2 bc = *(const float2*)(bcast + 2 * (epoch & 1u));
+    out = bc.x;
+    return bc.y != 0.0f;
 }
 
 // block-wide sum of a double over the 4 wavefronts; result valid in wave 0 lane 0
@@ -248,9 +251,9 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     unsigned short* hlist = (unsigned short*)(lds + RES_TILES_PER_WG * LTILE);    // [RES_MAX_HALO]
     int2* tbase = (int2*)((char*)hlist + ((RES_MAX_HALO * 8 + 15) / 16) * 16);    // [9] tile origin (x0, y0)
     float* moLUT = (float*)(tbase + RES_TILES_PER_WG + 1);                // [10] (+2 pad)
-    float* bcast = moLUT + 12;                                            // 2 floats + nhalo (int) + pad
-    int* nhalo = (int*)(bcast + 2);
-    double* wsum = (double*)(bcast + 4);                                  // 4 doubles
+    float* bcast = moLUT + 12;                                            // 2 x {sum, ok} + nhalo (int) + pad
+    int* nhalo = (int*)(bcast + 4);
+    double* wsum = (double*)(bcast + 6);                                  // 4 doubles (+ 1 at wsum[8])
     unsigned long long* gran_group = rd.gran + me.gran;
 
     const int nt = rd.ntiles[b];
