@@ -125,13 +125,37 @@ __device__ __forceinline__ float dot3(float ax, float ay, float aa, float bx, fl
 __device__ __forceinline__ int noff(int s, int W) { return s == 0 ? 1 : (s == 1 ? -1 : (s == 2 ? W : -W)); }
 
 // ---- reductions -------------------------------------------------------------------------------
-// wave64 shuffle tree on doubles, then one value per wavefront combined through LDS, then ONE
+// wave64 DPP tree on doubles, then one value per wavefront combined through LDS, then ONE
 // float64 atomic per workgroup into shard (workgroup index % NSHARD) of the target scalar.
+// Sum of a double over the 64 lanes with DPP row shifts / broadcasts (the order LLVM's wave scan uses on gfx9:
+// row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2-3).
+// The total is valid in LANE 63.  A __shfl tree costs six dependent ds_bpermute round trips (~0.3 us) per sum; the
+// resident kernel has four sums on the critical path of every iteration, the two-kernel path one at the head
+// (read_scalar) and one at the tail of every kernel.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi, lo);             // lanes without a source add +0.0
+}
+__device__ __forceinline__ double wave_sum_l63(double v)
+{
+    v = dpp_add_f64<0x111, 0xf>(v);                  // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);                  // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);                  // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);                  // row_shr:8   -> lane 15 of every row holds the row's sum
+    v = dpp_add_f64<0x142, 0xa>(v);                  // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc>(v);                  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return v;
+}
+
+// the same sum, returned in every lane (v_readlane of lane 63)
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
+    v = wave_sum_l63(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // all threads of the workgroup must call; blockDim = TILE_X*TILE_Y
@@ -179,9 +203,7 @@ __device__ __forceinline__ float read_scalar(const double* shards)
     double v = lane < (unsigned)NSHARD
                    ? __hip_atomic_load(shards + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                    : 0.0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return (float)v;
+    return (float)wave_sum(v);
 }
 
 }  // namespace arap

@@ -121,28 +121,6 @@ __device__ __forceinline__ float ld_sc1_f(const float* p)
     return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// Sum of a double over the 64 lanes with DPP row shifts / broadcasts (the order LLVM's wave scan uses on gfx9:
-// row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2-3).
-// The total is valid in LANE 63.  A __shfl tree costs six dependent ds_bpermute round trips (~0.3 us) per sum, and
-// an iteration has four sums on its critical path.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add_f64(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __hiloint2double(hi, lo);             // lanes without a source add +0.0
-}
-__device__ __forceinline__ double wave_sum_l63(double v)
-{
-    v = dpp_add_f64<0x111, 0xf>(v);                  // row_shr:1
-    v = dpp_add_f64<0x112, 0xf>(v);                  // row_shr:2
-    v = dpp_add_f64<0x114, 0xf>(v);                  // row_shr:4
-    v = dpp_add_f64<0x118, 0xf>(v);                  // row_shr:8   -> lane 15 of every row holds the row's sum
-    v = dpp_add_f64<0x142, 0xa>(v);                  // row_bcast:15 into rows 1 and 3
-    v = dpp_add_f64<0x143, 0xc>(v);                  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return v;
-}
-
 // Group-wide sum of one double per workgroup.  `part` is this workgroup's partial (valid in wave 0,
 // lane 0).  Wave 0 publishes it as two {tag, 32 bits} granules and sweeps the group's granules until
 // every tag equals `epoch`; lane k owns workgroups k, k+64, ... and adds their partials in that order,
