@@ -132,6 +132,8 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
+        // the whole group waits for the slowest publisher: this wave's few instructions go first on its SIMD
+        __builtin_amdgcn_s_setprio(3);
         unsigned long long* buf = gran_group + (size_t)(epoch & 1u) * wgs * 2;
         // lane 0 holds the partial: v_readfirstlane (a __shfl would be two ds_bpermute round trips)
         part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
@@ -170,6 +172,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
             if (out_d) *out_d = v;         // LDS double, read by the caller after the barrier below
             if (!ok) atomicExch(err, 0xDEAD0000u | (epoch & 0xffffu));
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     const float2 bc = *(const float2*)(bcast + 2 * (epoch & 1u));
