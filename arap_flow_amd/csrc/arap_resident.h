@@ -25,6 +25,7 @@
 // Arithmetic: the same float32 operation list as k_pcg_a / k_pcg_b (and the CPU oracle), for the
 // pixel-grid UrShape the frame solver always uses (CombinedSolver.h:207-221): d_s = U(c)-U(n) = -s.
 #pragma once
+#include <type_traits>
 #include "arap_device.h"
 
 namespace arap {
@@ -492,23 +493,29 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         float alpha = 0.f;
         if (sigma > 0.f) alpha = rho / sigma;
         acc = 0.0;
+        // (the store flavour is a compile-time constant inside the loop: as a run-time flag it costs six scalar
+        //  branches per slot)
+        auto phase_b = [&](auto fast_c) {
+            constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-        for (int j = 0; j < RES_SLOTS; ++j) {
-            unsigned f = fl[j];
-            asm volatile("" : "+v"(f));
-            const float mo = mo_[j], ma = ma_[j];
-            rx[j] = fmaf(-alpha, apx[j], rx[j]);
-            ry[j] = fmaf(-alpha, apy[j], ry[j]);
-            ra[j] = fmaf(-alpha, apa[j], ra[j]);
-            const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-            if (f & F_ACT) {
-                const unsigned i = (unsigned)(ibase[j] + loff);
-                st_pub_f2((float2*)((char*)zO_b + (size_t)(i * 8u)), make_float2(zx, zy), fast);   // (publishing border
-                st_pub_f((float*)((char*)zA_b + (size_t)(i * 4u)), za, fast);   // vertices only: slower, divergent stores)
+            for (int j = 0; j < RES_SLOTS; ++j) {
+                unsigned f = fl[j];
+                asm volatile("" : "+v"(f));
+                const float mo = mo_[j], ma = ma_[j];
+                rx[j] = fmaf(-alpha, apx[j], rx[j]);
+                ry[j] = fmaf(-alpha, apy[j], ry[j]);
+                ra[j] = fmaf(-alpha, apa[j], ra[j]);
+                const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
+                if (f & F_ACT) {
+                    const unsigned i = (unsigned)(ibase[j] + loff);
+                    st_pub_f2((float2*)((char*)zO_b + (size_t)(i * 8u)), make_float2(zx, zy), FAST);   // (publishing border
+                    st_pub_f((float*)((char*)zA_b + (size_t)(i * 4u)), za, FAST);   // vertices only: slower, divergent stores)
+                }
+                acc += (double)keep_if<5>(f, dot3(zx, zy, za, rx[j], ry[j], ra[j]));
+                __builtin_amdgcn_sched_barrier(0);
             }
-            acc += (double)keep_if<5>(f, dot3(zx, zy, za, rx[j], ry[j], ra[j]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        if (fast) phase_b(std::true_type{}); else phase_b(std::false_type{});
         // delta += alpha p while the z stores travel (own p from LDS, reads one slot ahead)
         {
             float2 Dp[2];
