@@ -6,10 +6,11 @@
 // workgroups empty).  Here every frame of the batch is solved by a GROUP of workgroups (256 threads, TWO
 // workgroups per CU so one computes while the other waits; the host sizes the group by the frame's
 // active tiles, ResWg below) that stays resident for all lIterations iterations:
-//   * r, delta, M^-1_A, flags and the transient Ap live in registers (9 tile slots of 64x4 vertices per
+//   * r, delta, M^-1, flags and the transient Ap live in registers (9 tile slots of 64x4 vertices per
 //     workgroup, one vertex per lane per slot),
 //   * the search direction p and cos/sin(A) live in LDS as 66x6 halo'd tiles (the stencil reads
-//     every neighbour from LDS),
+//     every neighbour from LDS, one tile slot ahead of the arithmetic; cells that are not active
+//     vertices are zero and invalid edges get a zero weight, so the phases are branch free),
 //   * per iteration the group exchanges only (a) two 16-byte partial sums per workgroup (all-gather
 //     of data-tagged granules, summed by every workgroup in the same fixed order -> deterministic) and
 //     (b) the preconditioned residual z of tile-border vertices, from which each workgroup rebuilds
@@ -202,9 +203,9 @@ __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 do
 
 // grid = 512 workgroups (groups x wgs), block = 256, dynamic LDS = RES_LDS_BYTES (two workgroups per CU)
 //
-// LDS map: 9 halo'd tiles x {px,py,pa,cos,sin} (71 280 B); halo list (u16 cell ids, <= 1224); tile
-// origins int2[9]; the 10-entry M^-1_O table; broadcast + reduction scratch.
-// Registers per lane: r(3) delta(3) Ap(3) M^-1_A flags for each of the 9 slots = 99.
+// LDS map: 9 halo'd tiles x {px,py,pa,cos,sin} (71 280 B); halo table (uint2 per halo cell, <= 1224; it
+// starts life as the u16 cell list); tile origins int2[9]; the 10-entry M^-1_O table; broadcast + reduction scratch.
+// Registers per lane: r(3) delta(3) Ap(3) M^-1_A M^-1_O flags for each of the 9 slots = 108 of 242.
 template <bool STAMPS>
 __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, ResDev rd, int L)
 {
