@@ -65,6 +65,7 @@ struct ResWg {
 struct ResDev {
     const int* tilelist;        // [batch][RES_MAX_TILES] linear tile index (ty * tilesX + tx) of active tiles
     const int* ntiles;          // [batch]
+    const int* tilepos;         // [batch][tilesX * tilesY] position of a tile in its frame's list, -1 = inactive
     unsigned long long* gran;   // [2 * RES_WGS * 2]  {tag << 32 | 32 value bits}
     unsigned* err;              // [1] 0 = ok
     const ResWg* wgmap;         // [RES_WGS] of this launch
@@ -237,6 +238,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     float* bcast = moLUT + 12;                                            // 2 x {sum, ok} + nhalo (int) + pad
     int* nhalo = (int*)(bcast + 4);
     double* wsum = (double*)(bcast + 6);                                  // 4 doubles (+ 1 at wsum[8])
+    unsigned* nbits = (unsigned*)(wsum + 10);                             // [16] bitmap: ranks owning my halo vertices
+    unsigned* nremote = nbits + 16;                                       // [1] some of them sit on another XCD
     unsigned long long* gran_group = rd.gran + me.gran;
 
     const int nt = rd.ntiles[b];
@@ -260,7 +263,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             if (fit) dO = fmaf(sl.wf, sl.wf, dO);
             moLUT[tid] = ginv(dO);
         }
-        if (tid == 0) *nhalo = 0;
+        if (tid == 0) { *nhalo = 0; *nremote = 0u; }
+        if (tid < 16) nbits[tid] = 0u;
     }
 
     // every cell of the halo'd tiles holds a finite value: cells outside the image or of unused slots are never
@@ -362,13 +366,20 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const int k = id / LPLANE, rem = id - k * LPLANE;
                 const int row = rem / LROW, col = rem - row * LROW;
                 const int2 tb = tbase[k];
-                e[u].x = (unsigned)((tb.x + col - 1) + W * (tb.y + row - 1));
+                const int gx = tb.x + col - 1, gy = tb.y + row - 1;
+                e[u].x = (unsigned)(gx + W * gy);
                 e[u].y = (unsigned)(k * (LTILE / 2) + rem) | ((unsigned)(k * LTILE + 4 * LPLANE + rem) << 16);
+                // which workgroup of the group owns that vertex (the even deal above)?  -> neighbour bitmap
+                const int pos = rd.tilepos[(size_t)b * pd.tilesX * pd.tilesY + (gy / TILE_Y) * pd.tilesX + gx / TILE_X];
+                const int nfull = textra * (tbase_n + 1);
+                const int owner = pos < nfull ? pos / (tbase_n + 1) : textra + (pos - nfull) / (tbase_n > 0 ? tbase_n : 1);
+                if (pos >= 0 && owner != rank) atomicOr(&nbits[(owner >> 5) & 15], 1u << (owner & 31));
             }
         }
         __syncthreads();                             // every u16 entry has been read
 #pragma unroll
-        for (int u = 0; u < RES_HALO_PER_THREAD; ++u) htab[tid + u * RES_THREADS] = e[u];
+        for (int u = 0; u < RES_HALO_PER_THREAD; ++u)
+            if (tid + u * RES_THREADS < RES_MAX_HALO) htab[tid + u * RES_THREADS] = e[u];     // 5 x 256 > 1224 entries
         // (each thread reads back only what it wrote: no barrier needed)
     }
     static_assert(RES_TILES_PER_WG * LTILE < 65536 && LTILE % 2 == 0, "halo table packs 16-bit cell offsets");
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------
     // every workgroup publishes xcc + 65536 xcc^2 through the placement-independent protocol (epoch 1);
     // the ids are all equal iff  wgs * sum(xcc^2) == (sum xcc)^2.
-    bool fast = false;
+    bool fast = false, zfast = false;                  // store flavour of the granules / of this workgroup's z
     {
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // HW_REG_XCC_ID
         float dummy;
@@ -401,6 +412,29 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         const double s2 = floor(tot / 65536.0), s1 = tot - 65536.0 * s2;
         fast = rd.allow_fast && ((double)wgs * s2 == s1 * s1);
         __syncthreads();
+        // A group that spans XCDs: a workgroup's z is read only by the owners of its halo vertices (the relation is
+        // symmetric), so if all of THOSE report this workgroup's XCD its z may stay in that L2 (plain stores) although
+        // the group's granules must be written through.  The epoch-1 granules still hold every workgroup's id.
+        if (!fast && rd.allow_fast && alive) {
+            if (wave == 0) {
+                const unsigned long long* buf = gran_group + (size_t)1 * wgs * 2;     // parity of epoch 1
+                bool remote = false;
+                for (int m = lane; m < wgs; m += 64) {
+                    if ((nbits[(m >> 5) & 15] >> (m & 31)) & 1u) {
+                        const unsigned long long lo = __hip_atomic_load(buf + 2 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long hi = __hip_atomic_load(buf + 2 * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const double val = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                        const double q2 = floor(val / 65536.0);
+                        remote = remote || (unsigned)(val - 65536.0 * q2) != xcc;
+                    }
+                }
+                if (__any(remote) && lane == 0) *nremote = 1u;
+            }
+            __syncthreads();
+            zfast = *nremote == 0u;
+        } else {
+            zfast = fast;
+        }
     }
     if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
     for (int l = 0; l < L && alive; ++l) {
@@ -516,7 +550,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (fast) phase_b(std::true_type{}); else phase_b(std::false_type{});
+        if (zfast) phase_b(std::true_type{}); else phase_b(std::false_type{});
         // delta += alpha p while the z stores travel (own p from LDS, reads one slot ahead)
         {
             float2 Dp[2];
@@ -599,7 +633,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     if (STAMPS && tid == 0) {
         unsigned long long* o = rd.stamps + (size_t)blockIdx.x * 8;
-        o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; o[6] = (unsigned long long)nh; o[7] = fast ? 1ull : 0ull;
+        o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; { unsigned pc = 0; for (int q = 0; q < 16; ++q) pc += __popc(nbits[q]); o[6] = (unsigned long long)nh | ((unsigned long long)pc << 32) | ((unsigned long long)*nremote << 48); } o[7] = (fast ? 1ull : 0ull) | (zfast ? 2ull : 0ull);
     }
     if (!alive) return;
     // ---- epilogue: delta back to the plan images for k_gn_update --------------------------------------

@@ -207,14 +207,16 @@ static void plan_enable_resident(Opt_Plan* p)
     const size_t sz_nt = align_up((size_t)p->batch * sizeof(int), 256);
     const size_t sz_gr = align_up((size_t)p->batch * 2 * RES_WGS * 2 * 8, 256);   // one block per launch of a step
     const size_t sz_map = align_up((size_t)p->batch * RES_WGS * sizeof(ResWg), 256);
-    HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map));
-    HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map, st->stream));
+    const size_t sz_tp = align_up((size_t)p->batch * p->pd.tilesX * p->pd.tilesY * sizeof(int), 256);
+    HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp));
+    HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp, st->stream));
     char* c = (char*)p->res_block;
-    p->rd.gran = (unsigned long long*)c; c += sz_gr;       // granules first: the per-launch memset zeroes
-    p->rd.tilelist = (const int*)c; c += sz_tl;            // exactly this 16-byte-multiple block
+    p->rd.gran = (unsigned long long*)c; c += sz_gr;
+    p->rd.tilelist = (const int*)c; c += sz_tl;
     p->rd.ntiles = (const int*)c; c += sz_nt;
     p->rd.err = (unsigned*)c; c += 256;
-    p->d_wgmap = (ResWg*)c;
+    p->d_wgmap = (ResWg*)c; c += sz_map;
+    p->rd.tilepos = (const int*)c;
     p->pd.res_err = p->rd.err;
     p->rd.stamps = nullptr;
     {
@@ -233,6 +235,26 @@ static void plan_enable_resident(Opt_Plan* p)
         HC(hipMemset(p->rd.stamps, 0, RES_WGS * 8 * sizeof(unsigned long long)));
     }
     p->res_capable = true;
+}
+
+// active-tile list of one slot (ascending tile indices), its length and the inverse map tile -> position
+static void plan_upload_tiles(Opt_Plan* p, int slot, const std::vector<int>& tiles)
+{
+    const int nt = (int)tiles.size();
+    const int nt_all = p->pd.tilesX * p->pd.tilesY;
+    p->h_ntiles[slot] = nt;
+    if (!p->res_capable) return;
+    HC(hipStreamSynchronize(p->st->stream));
+    if (nt <= RES_MAX_TILES) {
+        std::vector<int> pos(nt_all, -1);
+        for (int i = 0; i < nt; ++i) pos[tiles[i]] = i;
+        if (nt > 0)
+            HC(hipMemcpy((void*)(p->rd.tilelist + (size_t)slot * RES_MAX_TILES), tiles.data(), sizeof(int) * nt,
+                         hipMemcpyHostToDevice));
+        HC(hipMemcpy((void*)(p->rd.tilepos + (size_t)slot * nt_all), pos.data(), sizeof(int) * nt_all,
+                     hipMemcpyHostToDevice));
+    }
+    HC(hipMemcpy((void*)(p->rd.ntiles + slot), &nt, sizeof(int), hipMemcpyHostToDevice));
 }
 
 // Opt_ProblemInit: look at the caller's Mask and UrShape once (the reference's init also blocks on a device
@@ -257,10 +279,7 @@ static void plan_analyse_for_resident(Opt_Plan* p)
     const int nt = (int)tiles.size();
     p->h_ntiles[0] = nt;                        // also steers the automatic phase-A variant of the two-kernel path
     if (notgrid || !p->res_capable || !st->use_resident || nt > RES_MAX_TILES) return;
-    if (nt > 0)
-        HC(hipMemcpyAsync((void*)p->rd.tilelist, tiles.data(), sizeof(int) * nt, hipMemcpyHostToDevice, st->stream));
-    HC(hipMemcpyAsync((void*)p->rd.ntiles, &nt, sizeof(int), hipMemcpyHostToDevice, st->stream));
-    HC(hipStreamSynchronize(st->stream));       // `tiles` is a local
+    plan_upload_tiles(p, 0, tiles);
     p->opt_res_ok = true;
     p->opt_res_slot = p->hslots[0];
 }
@@ -367,9 +386,13 @@ static int resident_deal(const Opt_Plan* p, int nb, std::vector<ResWg>* map_out,
         map.assign((size_t)nsets * RES_WGS, idle);
         for (int set = 0; set < nsets; ++set)
             for (int i = 0; i < RES_WGS; ++i) {
+                // a group takes 8 / groups whole XCDs and every XCD holds a run of 64 consecutive ranks: tiles are
+                // dealt in list (row-major) order, so nearly all of a workgroup's halo neighbours share its XCD
+                // and only the workgroups next to a run boundary must publish z write-through (arap_resident.h)
                 int g, rank;
-                if (groups >= 8) { const int j = i >> 3; g = (i & 7) + 8 * (j / wgs); rank = j % wgs; }
-                else { g = i % groups; rank = i / groups; }
+                const int x = i & 7, j = i >> 3;
+                if (groups >= 8) { g = x + 8 * (j / wgs); rank = j % wgs; }
+                else { const int xper = 8 / groups; g = x / xper; rank = (x % xper) * XW + j; }
                 const int b = set * groups + g;
                 if (b < nb) map[(size_t)set * RES_WGS + i] = ResWg{b, rank, wgs, 4 * g * wgs};
             }
@@ -1255,15 +1278,8 @@ int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rg
                 if (any) tiles.push_back(ty * tX + tx);
             }
     }
-    s->plan->h_ntiles[slot] = (int)tiles.size();
     HC(hipStreamSynchronize(s->st->stream));
-    if (s->plan->res_capable) {
-        const int nt = (int)tiles.size();
-        if (nt <= RES_MAX_TILES && nt > 0)
-            HC(hipMemcpy((void*)(s->plan->rd.tilelist + (size_t)slot * RES_MAX_TILES), tiles.data(),
-                         sizeof(int) * nt, hipMemcpyHostToDevice));
-        HC(hipMemcpy((void*)(s->plan->rd.ntiles + slot), &nt, sizeof(int), hipMemcpyHostToDevice));
-    }
+    plan_upload_tiles(s->plan, (int)slot, tiles);
     const FrameDev& f = s->hfr[slot];
     HC(hipMemcpy(f.T, T.data(), N * sizeof(float2), hipMemcpyHostToDevice));
     HC(hipMemcpy(f.mask, mask_red, N, hipMemcpyHostToDevice));

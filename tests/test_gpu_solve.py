@@ -170,9 +170,11 @@ def test_resident_and_two_kernel_paths_are_bit_identical(gpu_state):
     operation list: identical Offset/Angle bits.  Covers 8, 4 and 1 frames in flight and a frame that is
     too large for eight groups (so the groups widen)."""
     from arap_flow_amd import synth
-    cases = [(854, 480, 5, 1, (2, 2, 60)), (320, 200, 2, 3, (3, 2, 40)), (200, 120, 8, 1, (1, 3, 25))]
+    cases = [(854, 480, 5, 1, (2, 2, 60)), (320, 200, 2, 3, (3, 2, 40)), (200, 120, 8, 1, (1, 3, 25)),
+             (854, 480, 2, 0, (1, 2, 60)),      # K = 0: every vertex active, 1680 tiles: groups of 256 workgroups on 4 XCDs
+             (1920, 1080, 3, 1, (1, 2, 40))]    # ~2000 tiles: groups spanning XCDs with sparse masks
     for W, H, nfr, K, sched in cases:
-        frames = [synth.make_frame(W, H, seed=10 + s, K=K, fd=2) for s in range(nfr)]
+        frames = [synth.make_frame(W, H, seed=10 + s, K=max(K, 1), fd=2, full_mask=(K == 0)) for s in range(nfr)]
         outs = []
         for resident in (True, False):
             gpu_state.set_resident(resident)
