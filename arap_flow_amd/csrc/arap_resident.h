@@ -52,6 +52,10 @@ static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two wor
 #define RES_PAIR_SLOTS 1      // slots of phase A the scheduler may interleave (register pressure vs latency hiding)
 #endif
 constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
+// granules of one launch (u64 entries): [2 parity][wgs][2] per group, packed back to back (4 per workgroup), then the
+// second-level granules of groups that span XCDs: [2 parity][8 XCD runs][2] for up to 4 such groups
+constexpr int RES_GRAN_L1 = 2 * RES_WGS * 2;
+constexpr int RES_GRAN_PER_LAUNCH = RES_GRAN_L1 + 4 * 32;
 
 // One entry per workgroup of a launch, written by the host (arapopt.hip: plan_resident_pack): which solve the
 // workgroup works on, its rank in that solve's group, the group's size and where the group's granules start.
@@ -66,7 +70,7 @@ struct ResDev {
     const int* tilelist;        // [batch][RES_MAX_TILES] linear tile index (ty * tilesX + tx) of active tiles
     const int* ntiles;          // [batch]
     const int* tilepos;         // [batch][tilesX * tilesY] position of a tile in its frame's list, -1 = inactive
-    unsigned long long* gran;   // [2 * RES_WGS * 2]  {tag << 32 | 32 value bits}
+    unsigned long long* gran;   // [RES_GRAN_PER_LAUNCH]  {tag << 32 | 32 value bits}
     unsigned* err;              // [1] 0 = ok
     const ResWg* wgmap;         // [RES_WGS] of this launch
     int allow_fast;             // 0: always use the write-through (placement independent) store flavour
@@ -174,6 +178,84 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
             *(float2*)(bcast + 2 * (epoch & 1u)) = make_float2((float)v, ok ? 1.0f : 0.0f);
             if (out_d) *out_d = v;         // LDS double, read by the caller after the barrier below
             if (!ok) atomicExch(err, 0xDEAD0000u | (epoch & 0xffffu));
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+    const float2 bc = *(const float2*)(bcast + 2 * (epoch & 1u));
+    out = bc.x;
+    return bc.y != 0.0f;
+}
+
+// The same sum for a group that spans XCDs (wgs = 64 nsub; XCD run `sub` holds ranks 64 sub .. 64 sub + 63, see
+// arapopt.hip: resident_deal).  A flat all-gather would have every workgroup poll every granule through the fabric
+// (256 pollers x 256 granules: measured 3.4 us per wait against 0.85 us inside one XCD).  Two levels instead:
+//   1. all-gather inside the XCD run exactly as above (plain granule stores when the run really sits on one XCD:
+//      `subfast`, checked at run time like `fast`) -> every workgroup of the run knows its run's sum S_sub;
+//   2. the first workgroup of every run publishes S_sub write-through; every workgroup polls those nsub (<= 8)
+//      granules and adds them in run order -> the same bits everywhere, deterministic.
+// z visibility is transitive: a workgroup's z stores have landed before its level-1 granule, a run's leader writes
+// the level-2 granule only after it has seen every level-1 granule of its run, and a consumer reads z only after it
+// has seen every level-2 granule.
+__device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigned long long* gran_group,
+                                            unsigned long long* gran2 /* [2][8][2] of this group */, int rank, int wgs,
+                                            float* bcast, unsigned* err, float& out, bool subfast)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        const int sub = rank >> 6, srank = rank & 63, nsub = wgs >> 6;
+        unsigned long long* buf = gran_group + (size_t)sub * 256 + (size_t)(epoch & 1u) * 128;
+        part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
+                                __builtin_amdgcn_readfirstlane(__double2loint(part)));
+        if (lane < 2) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(part);
+            const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+            const unsigned long long gv = ((unsigned long long)epoch << 32) | hw;
+            if (subfast)
+                __hip_atomic_store(buf + srank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else
+                __hip_atomic_store(buf + srank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        double v = 0.0;
+        bool ok = false;
+        for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {           // level 1: lane k <-> workgroup k of the run
+            const unsigned long long lo = __hip_atomic_load(buf + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(buf + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+            ok = __all((unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const double ssub = wave_sum(v);                                      // uniform
+        unsigned long long* buf2 = gran2 + (size_t)(epoch & 1u) * 16;
+        if (ok && srank == 0 && lane < 2) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(ssub);
+            const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+            __hip_atomic_store(buf2 + sub * 2 + lane, ((unsigned long long)epoch << 32) | hw, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool ok2 = false;
+        v = 0.0;
+        if (ok) {
+            for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {       // level 2: lane k <-> run k
+                bool mine_ok = true;
+                v = 0.0;
+                if (lane < nsub) {
+                    const unsigned long long lo = __hip_atomic_load(buf2 + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long hi = __hip_atomic_load(buf2 + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                    mine_ok = (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+                }
+                ok2 = __all(mine_ok);
+                if (ok2) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        v = wave_sum_l63(v);
+        if (lane == 63) {
+            *(float2*)(bcast + 2 * (epoch & 1u)) = make_float2((float)v, ok2 ? 1.0f : 0.0f);
+            if (!ok2) atomicExch(err, 0xDEAD8000u | (epoch & 0x7fffu));
         }
         __builtin_amdgcn_s_setprio(0);
     }
@@ -403,6 +485,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // every workgroup publishes xcc + 65536 xcc^2 through the placement-independent protocol (epoch 1);
     // the ids are all equal iff  wgs * sum(xcc^2) == (sum xcc)^2.
     bool fast = false, zfast = false;                  // store flavour of the granules / of this workgroup's z
+    bool hier = false, subfast = false;                // two-level sums for a group that spans XCDs (group_sum_h)
+    unsigned long long* const gran2 = rd.gran + RES_GRAN_L1 + (me.gran / (4 * me.wgs)) * 32;
     {
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // HW_REG_XCC_ID
         float dummy;
@@ -412,29 +496,40 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         const double s2 = floor(tot / 65536.0), s1 = tot - 65536.0 * s2;
         fast = rd.allow_fast && ((double)wgs * s2 == s1 * s1);
         __syncthreads();
-        // A group that spans XCDs: a workgroup's z is read only by the owners of its halo vertices (the relation is
-        // symmetric), so if all of THOSE report this workgroup's XCD its z may stay in that L2 (plain stores) although
-        // the group's granules must be written through.  The epoch-1 granules still hold every workgroup's id.
+        // A group that spans XCDs.  (a) A workgroup's z is read only by the owners of its halo vertices (the relation is
+        // symmetric), so if all of THOSE report this workgroup's XCD its z may stay in that L2 (plain stores).  (b) The
+        // group's sums are gathered in two levels (group_sum_h); the first level uses plain granule stores if the 64
+        // workgroups of this XCD run really share an XCD.  The epoch-1 granules still hold every workgroup's id (a
+        // granule that a faster workgroup has already reused carries another tag and counts as "elsewhere").
+        hier = !fast && wgs > 64 && (wgs & 63) == 0;
         if (!fast && rd.allow_fast && alive) {
             if (wave == 0) {
                 const unsigned long long* buf = gran_group + (size_t)1 * wgs * 2;     // parity of epoch 1
-                bool remote = false;
+                bool remote = false, elsewhere = false;
                 for (int m = lane; m < wgs; m += 64) {
-                    if ((nbits[(m >> 5) & 15] >> (m & 31)) & 1u) {
+                    const bool nb = ((nbits[(m >> 5) & 15] >> (m & 31)) & 1u) != 0u;
+                    const bool same_run = hier && (m >> 6) == (rank >> 6);
+                    if (nb || same_run) {
                         const unsigned long long lo = __hip_atomic_load(buf + 2 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const unsigned long long hi = __hip_atomic_load(buf + 2 * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const double val = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
                         const double q2 = floor(val / 65536.0);
-                        remote = remote || (unsigned)(val - 65536.0 * q2) != xcc;
+                        const bool other = (unsigned)(lo >> 32) != 1u || (unsigned)(hi >> 32) != 1u ||
+                                           (unsigned)(val - 65536.0 * q2) != xcc;
+                        remote = remote || (nb && other);
+                        elsewhere = elsewhere || (same_run && other);
                     }
                 }
-                if (__any(remote) && lane == 0) *nremote = 1u;
+                const unsigned any_remote = __any(remote) ? 1u : 0u, any_elsewhere = __any(elsewhere) ? 2u : 0u;
+                if (lane == 0) *nremote = any_remote | any_elsewhere;      // (the votes need every lane: outside the if)
             }
             __syncthreads();
-            zfast = *nremote == 0u;
+            zfast = (*nremote & 1u) == 0u;
+            subfast = hier && (*nremote & 2u) == 0u;
         } else {
             zfast = fast;
         }
+        __syncthreads();
     }
     if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
     for (int l = 0; l < L && alive; ++l) {
@@ -520,7 +615,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #undef RES_LOAD
         float sigma;
         RES_STAMP(tA);
-        alive = group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast);
+        alive = hier ? group_sum_h(block_sum8(acc, wsum), 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
+                     : group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast);
         if (!alive) break;
         RES_STAMP(tS1);
         // ---------------- phase B: alpha, r, z, rho', delta ---------------------------------------------
@@ -575,7 +671,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         float rhoNew;
         RES_STAMP(tB);
         // (every storing wave drains inside block_sum8, before the workgroup barrier: R1)
-        alive = group_sum(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast);
+        alive = hier ? group_sum_h(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
+                     : group_sum(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast);
         if (!alive) break;
         RES_STAMP(tS2);
         float beta = 0.f;
@@ -633,7 +730,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     if (STAMPS && tid == 0) {
         unsigned long long* o = rd.stamps + (size_t)blockIdx.x * 8;
-        o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; { unsigned pc = 0; for (int q = 0; q < 16; ++q) pc += __popc(nbits[q]); o[6] = (unsigned long long)nh | ((unsigned long long)pc << 32) | ((unsigned long long)*nremote << 48); } o[7] = (fast ? 1ull : 0ull) | (zfast ? 2ull : 0ull);
+        o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; { unsigned pc = 0; for (int q = 0; q < 16; ++q) pc += __popc(nbits[q]); o[6] = (unsigned long long)nh | ((unsigned long long)pc << 32) | ((unsigned long long)*nremote << 48); } o[7] = (fast ? 1ull : 0ull) | (zfast ? 2ull : 0ull) | (hier ? 4ull : 0ull) | (subfast ? 8ull : 0ull);
     }
     if (!alive) return;
     // ---- epilogue: delta back to the plan images for k_gn_update --------------------------------------

@@ -205,7 +205,7 @@ static void plan_enable_resident(Opt_Plan* p)
     }
     const size_t sz_tl = align_up((size_t)p->batch * RES_MAX_TILES * sizeof(int), 256);
     const size_t sz_nt = align_up((size_t)p->batch * sizeof(int), 256);
-    const size_t sz_gr = align_up((size_t)p->batch * 2 * RES_WGS * 2 * 8, 256);   // one block per launch of a step
+    const size_t sz_gr = align_up((size_t)p->batch * RES_GRAN_PER_LAUNCH * 8, 256);   // one block per launch of a step
     const size_t sz_map = align_up((size_t)p->batch * RES_WGS * sizeof(ResWg), 256);
     const size_t sz_tp = align_up((size_t)p->batch * p->pd.tilesX * p->pd.tilesY * sizeof(int), 256);
     HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp));
@@ -569,7 +569,7 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
     const dim3 g = p->grid(), b = p->blk();
     const bool res = plan_resident_eligible(p);
     PlanDev pd = p->pd;
-    const size_t gran_per_launch = (size_t)2 * RES_WGS * 2;              // u64 entries
+    const size_t gran_per_launch = RES_GRAN_PER_LAUNCH;                  // u64 entries
     if (res) {
         // k_gn_prep zeroes slot 0 of `red` (rho_0) and the granules of every launch of this step: no memset nodes.
         // Granule tags restart at 1 in every launch (cdna guide G16 "re-initialise every call").

@@ -17,7 +17,7 @@ for resident in (True, False):
         out = np.zeros((512, 8), np.uint64)
         st.lib.ArapFlow_SolverStamps(fs.h, out.ctypes.data)
         fl = out[:, 7]
-        print("flags (1 = granules fast, 2 = z fast):", {int(k): int((fl == k).sum()) for k in np.unique(fl)})
+        print("flags (1 granules fast, 2 z fast, 4 two-level sums, 8 first level plain):", {int(k): int((fl == k).sum()) for k in np.unique(fl)})
         print("neighbour counts", np.unique((out[:, 6] >> 32) & 0xffff, return_counts=True), "nremote", np.unique(out[:, 6] >> 48, return_counts=True))
         xs = np.arange(512) & 7
         for x in range(8):
