@@ -22,15 +22,16 @@ o = out.astype(np.float64)
 used = o[:, 0] > 0
 us = o[used, :5] * 0.01 / L          # 100 MHz ticks -> us per iteration
 print("frames", B, "wall us/iter (4 GN steps incl. launches):", dt / (4 * L) * 1e6, fs.stats())
-print("same-XCD fast path in", int(o[used, 7].sum()), "of", int(used.sum()), "workgroups")
-print("workgroups active", used.sum(), "tiles/WG", o[used, 5].min(), o[used, 5].max(), "halo cells", o[used, 6].min(), o[used, 6].max())
+fl = out[:, 7][used]
+print("of", int(used.sum()), "workgroups:", int((fl & 1).astype(bool).sum()), "in a group on one XCD,", int((fl & 4).astype(bool).sum()), "in a group with two-level sums,", int((fl & 2).astype(bool).sum()), "keep their z in L2 (plain stores)")
+print("workgroups active", used.sum(), "tiles/WG", o[used, 5].min(), o[used, 5].max(), "halo cells", (out[:, 6][used] & 0xffffffff).min(), (out[:, 6][used] & 0xffffffff).max())
 for n, col in zip(["phaseA", "wait1", "phaseB+drain", "wait2", "update"], us.T):
     print("%-14s mean %.2f  min %.2f  max %.2f us" % (n, col.mean(), col.min(), col.max()))
 print("sum of means %.2f us" % us.mean(0).sum())
 # per-workgroup view of one group (the workgroups of XCD 0: blockIdx & 7 == 0), sorted by tiles then phase A time
 idx = np.arange(512)
 g0 = used & ((idx & 7) == 0)
-rows = sorted(zip(o[g0, 5], o[g0, 6], *(o[g0, c] * 0.01 / L for c in range(5)), idx[g0] >> 3), key=lambda r: (r[0], r[2]))
+rows = sorted(zip(o[g0, 5], (out[:, 6] & 0xffffffff).astype(np.float64)[g0], *(o[g0, c] * 0.01 / L for c in range(5)), idx[g0] >> 3), key=lambda r: (r[0], r[2]))
 print("XCD 0 workgroups: tiles halo | phaseA wait1 phaseB wait2 update | local index")
 for r in rows:
     print("%3d %5d | %5.2f %5.2f %5.2f %5.2f %5.2f | %2d" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]))
