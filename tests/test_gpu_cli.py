@@ -195,6 +195,29 @@ def test_bench_two_ranks_under_torch_distributed_run(tmp_path):
     assert "roofline" in d and "cpu_baseline" not in d
 
 
+def test_resident_kernel_without_the_xcd_fast_paths(tmp_path):
+    """ARAPOPT_NO_XCD_FAST=1 makes the resident kernel publish everything write-through, as it must when the workgroups
+    of a group (or of an XCD run of a wide group) do not share an XCD.  Placement is the hardware's choice, so this
+    flavour is exercised explicitly: a group on one XCD and a group that spans XCDs both give the oracle's bits."""
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from arap_flow_amd import opt, synth\n"
+        "from oracle import oracle as orc\n"
+        "st = opt.State()\n"
+        "for (W, H, full) in ((160, 96, False), (854, 480, True)):\n"
+        "    f = synth.make_frame(W, H, seed=5, full_mask=full)\n"
+        "    fs = opt.FrameSolver(st, W, H, batch=1); fs.set_frame(0, f['mask_red'], f['constraints'])\n"
+        "    fs.solve(1, 1, 2, 20); r = fs.results(0, want_rgb=False)\n"
+        "    assert fs.stats()['resident_launches'] > 0\n"
+        "    O, A, c = orc.frame(f['mask_red'], f['constraints'], numIter=1, nIterations=2, lIterations=20, dtype=np.float32, mode=1, trig=1)\n"
+        "    assert np.array_equal(r['offset'], O) and np.array_equal(r['angle'], A), (W, H)\n"
+        "    fs.close()\n"
+        "print('write-through ok')\n" % ROOT)
+    env = dict(os.environ, ARAPOPT_NO_XCD_FAST="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "write-through ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_resident_failure_falls_back_to_two_kernel_path(tmp_path):
     """ARAPOPT_FORCE_RES_FAIL=1 makes every resident launch report a timed-out group wait (what happens when the GPU
     is shared and the 512 workgroups are not co-resident).  The frame solver and the drop-in path must notice, redo the
