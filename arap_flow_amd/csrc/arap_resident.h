@@ -53,9 +53,11 @@ static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two wor
 #endif
 constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
 // granules of one launch (u64 entries): [2 parity][wgs][2] per group, packed back to back (4 per workgroup), then the
-// second-level granules of groups that span XCDs: [2 parity][8 XCD runs][2] for up to 4 such groups
+// second-level granules of groups that span XCDs: [2 parity][8 XCD runs][16: one line each] for up to 4 such groups
 constexpr int RES_GRAN_L1 = 2 * RES_WGS * 2;
-constexpr int RES_GRAN_PER_LAUNCH = RES_GRAN_L1 + 4 * 32;
+constexpr int RES_GRAN2_STRIDE = 16;            // u64 per second-level granule pair: one 128-byte line per XCD run
+constexpr int RES_GRAN2_GROUP = 2 * 8 * RES_GRAN2_STRIDE;
+constexpr int RES_GRAN_PER_LAUNCH = RES_GRAN_L1 + 4 * RES_GRAN2_GROUP;
 
 // One entry per workgroup of a launch, written by the host (arapopt.hip: plan_resident_pack): which solve the
 // workgroup works on, its rank in that solve's group, the group's size and where the group's granules start.
@@ -198,7 +200,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
 // the level-2 granule only after it has seen every level-1 granule of its run, and a consumer reads z only after it
 // has seen every level-2 granule.
 __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigned long long* gran_group,
-                                            unsigned long long* gran2 /* [2][8][2] of this group */, int rank, int wgs,
+                                            unsigned long long* gran2 /* [2][8][16] of this group */, int rank, int wgs,
                                             float* bcast, unsigned* err, float& out, bool subfast)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -228,11 +230,11 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
             __builtin_amdgcn_s_sleep(1);
         }
         const double ssub = wave_sum(v);                                      // uniform
-        unsigned long long* buf2 = gran2 + (size_t)(epoch & 1u) * 16;
+        unsigned long long* buf2 = gran2 + (size_t)(epoch & 1u) * (8 * RES_GRAN2_STRIDE);
         if (ok && srank == 0 && lane < 2) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(ssub);
             const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
-            __hip_atomic_store(buf2 + sub * 2 + lane, ((unsigned long long)epoch << 32) | hw, __ATOMIC_RELAXED,
+            __hip_atomic_store(buf2 + sub * RES_GRAN2_STRIDE + lane, ((unsigned long long)epoch << 32) | hw, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         }
         bool ok2 = false;
@@ -242,8 +244,8 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
                 bool mine_ok = true;
                 v = 0.0;
                 if (lane < nsub) {
-                    const unsigned long long lo = __hip_atomic_load(buf2 + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned long long hi = __hip_atomic_load(buf2 + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long lo = __hip_atomic_load(buf2 + RES_GRAN2_STRIDE * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long hi = __hip_atomic_load(buf2 + RES_GRAN2_STRIDE * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
                     mine_ok = (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
                 }
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // the ids are all equal iff  wgs * sum(xcc^2) == (sum xcc)^2.
     bool fast = false, zfast = false;                  // store flavour of the granules / of this workgroup's z
     bool hier = false, subfast = false;                // two-level sums for a group that spans XCDs (group_sum_h)
-    unsigned long long* const gran2 = rd.gran + RES_GRAN_L1 + (me.gran / (4 * me.wgs)) * 32;
+    unsigned long long* const gran2 = rd.gran + RES_GRAN_L1 + (me.gran / (4 * me.wgs)) * RES_GRAN2_GROUP;
     {
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // HW_REG_XCC_ID
         float dummy;
