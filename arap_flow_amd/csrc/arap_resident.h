@@ -488,7 +488,9 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // the ids are all equal iff  wgs * sum(xcc^2) == (sum xcc)^2.
     bool fast = false, zfast = false;                  // store flavour of the granules / of this workgroup's z
     bool hier = false, subfast = false;                // two-level sums for a group that spans XCDs (group_sum_h)
-    unsigned long long* const gran2 = rd.gran + RES_GRAN_L1 + (me.gran / (4 * me.wgs)) * RES_GRAN2_GROUP;
+    // second-level granules of a group that spans XCDs: it starts at an even bin (blockIdx & 7) - (rank >> 6)
+    unsigned long long* const gran2 =
+        rd.gran + RES_GRAN_L1 + ((((int)(blockIdx.x & 7u) - (me.rank >> 6)) >> 1) & 3) * RES_GRAN2_GROUP;
     {
         const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;     // HW_REG_XCC_ID
         float dummy;

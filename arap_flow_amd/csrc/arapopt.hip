@@ -300,62 +300,102 @@ static bool plan_resident_eligible(const Opt_Plan* p)
 }
 
 // Deal the solves of the current batch to resident launches and their 512 workgroups (ResWg tables).
-//  * A solve of nt active tiles needs ceil(nt / 9) workgroups.  If every solve fits the 64 workgroups that land on
-//    one XCD (blockIdx & 7 equal, local index blockIdx >> 3), the solves are bin-packed into the 8 XCDs of as few
-//    launches as first-fit-decreasing needs, spread evenly over those bins (least-loaded first), and every group is
-//    then widened to use its bin's spare workgroups (fewer tiles per workgroup = shorter phases).  Groups of one
-//    bin take consecutive local indices, so the two workgroups of a CU (j, j + 32) usually serve different solves.
-//  * Otherwise (a solve spans XCDs) the launch is cut into 4, 2 or 1 equal groups, group = blockIdx % groups.
+// A launch is 8 bins of 64 workgroups: the workgroups that land on one XCD (blockIdx & 7 equal, local index
+// blockIdx >> 3).  A solve of nt active tiles needs ceil(nt / 9) workgroups.
+//  * A solve that fits one bin shares it with others: the narrow solves are bin-packed into as few launches as
+//    first-fit-decreasing needs, spread evenly over the free bins (least-loaded first), and every group is then
+//    widened to use its bin's spare workgroups (fewer tiles per workgroup = shorter phases).  Groups of one bin take
+//    consecutive local indices, so the two workgroups of a CU (j, j + 32) usually serve different solves.
+//  * A wider solve takes 2, 4 or 8 whole bins, aligned to its width.  Every bin holds a run of 64 consecutive ranks:
+//    tiles are dealt in list (row-major) order, so nearly all of a workgroup's halo neighbours share its XCD; only
+//    the workgroups next to a run boundary publish z write-through and the group's sums are gathered in two levels
+//    (arap_resident.h).
 // Returns the number of launches; fills `map` ([launches][RES_WGS]) and `inflight_out` when given.
 static int resident_deal(const Opt_Plan* p, int nb, std::vector<ResWg>* map_out, int* inflight_out)
 {
-    std::vector<int> need(nb);
+    const int XW = RES_WGS / 8;                                  // workgroups per XCD
+    std::vector<int> need(nb), width(nb);
     int mx = 1;
     for (int b = 0; b < nb; ++b) {
         need[b] = (p->h_ntiles[b] + RES_TILES_PER_WG - 1) / RES_TILES_PER_WG;
         if (need[b] < 1) need[b] = 1;
         mx = need[b] > mx ? need[b] : mx;
+        width[b] = 1;                                            // bins taken: 1 (shared) or 2, 4, 8 (whole)
+        while (width[b] * XW < need[b]) width[b] *= 2;
     }
     std::vector<ResWg> map;
     int nsets = 0, inflight = 0;
     const ResWg idle = {-1, 0, 0, 0};
     int forced = 0;
     {
-        const char* fg = getenv("ARAPOPT_RES_GROUPS");           // experiments only: equal groups as below
+        const char* fg = getenv("ARAPOPT_RES_GROUPS");           // experiments only: equal groups
         if (fg && atoi(fg) > 0) forced = atoi(fg);
     }
-    const int XW = RES_WGS / 8;                                  // workgroups per XCD
-    if (mx <= XW && !forced) {
+    if (forced && forced <= RES_MAX_GROUPS && (RES_WGS / forced) >= mx && (RES_WGS % forced) == 0) {
+        const int groups = forced, wgs = RES_WGS / groups;
+        nsets = (nb + groups - 1) / groups;
+        map.assign((size_t)nsets * RES_WGS, idle);
+        for (int set = 0; set < nsets; ++set)
+            for (int i = 0; i < RES_WGS; ++i) {
+                int g, rank;
+                const int x = i & 7, j = i >> 3;
+                if (groups >= 8) { g = x + 8 * (j / wgs); rank = j % wgs; }
+                else { const int xper = 8 / groups; g = x / xper; rank = (x % xper) * XW + j; }
+                const int sb = set * groups + g;
+                if (sb < nb) map[(size_t)set * RES_WGS + i] = ResWg{sb, rank, wgs, 4 * g * wgs};
+            }
+        inflight = nb < groups ? nb : groups;
+    } else {
         std::vector<int> order(nb);
         for (int b = 0; b < nb; ++b) order[b] = b;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return need[a] > need[c]; });
-        // (1) number of launches: first fit decreasing
-        std::vector<int> load;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+            return width[a] != width[c] ? width[a] > width[c] : need[a] > need[c];
+        });
+        // bin state over all launches: owner >= 0: a wide solve holds the whole bin; owner == -1: shared / free
+        std::vector<int> owner, load;
+        auto add_launch = [&]() { owner.insert(owner.end(), 8, -1); load.insert(load.end(), 8, 0); };
+        // (1) wide solves: first launch with `width` aligned bins that nothing has touched yet
         for (int b : order) {
-            size_t k = 0;
-            while (k < load.size() && load[k] + need[b] > XW) ++k;
-            if (k == load.size()) load.insert(load.end(), 8, 0);
-            load[k] += need[b];
+            if (width[b] == 1) continue;
+            size_t at = owner.size();
+            for (size_t k = 0; k + width[b] <= owner.size() && at == owner.size(); k += width[b]) {
+                bool free_run = true;
+                for (int q = 0; q < width[b]; ++q) free_run = free_run && owner[k + q] < 0 && load[k + q] == 0;
+                if (free_run) at = k;
+            }
+            if (at == owner.size()) add_launch();                // 8 is a multiple of every width: `at` is aligned
+            for (int q = 0; q < width[b]; ++q) { owner[at + q] = b; load[at + q] = XW; }
         }
-        nsets = (int)load.size() / 8;
-        // (2) spread: least-loaded bin that still fits; keep the first-fit deal if that ever fails
-        std::vector<std::vector<int>> bins(load.size());
-        std::vector<int> l2(load.size(), 0);
+        // (2) narrow solves: number of launches by first fit decreasing over the shared bins ...
+        std::vector<int> ff = load;
+        for (int b : order) {
+            if (width[b] != 1) continue;
+            size_t k = 0;
+            while (k < ff.size() && ff[k] + need[b] > XW) ++k;
+            if (k == ff.size()) { add_launch(); ff.insert(ff.end(), 8, 0); }
+            ff[k] += need[b];
+        }
+        nsets = (int)owner.size() / 8;
+        // ... then spread: least-loaded shared bin that still fits; keep the first-fit deal if that ever fails
+        std::vector<std::vector<int>> bins(owner.size());
+        std::vector<int> l2 = load;
         bool ok = true;
         for (int b : order) {
+            if (width[b] != 1) continue;
             int best = -1;
             for (size_t k = 0; k < l2.size(); ++k)
-                if (l2[k] + need[b] <= XW && (best < 0 || l2[k] < l2[best])) best = (int)k;
+                if (owner[k] < 0 && l2[k] + need[b] <= XW && (best < 0 || l2[k] < l2[best])) best = (int)k;
             if (best < 0) { ok = false; break; }
             l2[best] += need[b];
             bins[best].push_back(b);
         }
         if (!ok) {
             for (auto& v : bins) v.clear();
-            std::fill(l2.begin(), l2.end(), 0);
+            l2 = load;
             for (int b : order) {
+                if (width[b] != 1) continue;
                 size_t k = 0;
-                while (l2[k] + need[b] > XW) ++k;
+                while (l2[k] + need[b] > XW) ++k;                // a wide solve's bins are full: skipped
                 l2[k] += need[b];
                 bins[k].push_back(b);
             }
@@ -364,11 +404,22 @@ static int resident_deal(const Opt_Plan* p, int nb, std::vector<ResWg>* map_out,
         for (int set = 0; set < nsets; ++set) {
             int ordinal = 0, count = 0;                          // workgroups / solves dealt in this launch
             for (int x = 0; x < 8; ++x) {
-                const std::vector<int>& v = bins[(size_t)set * 8 + x];
-                const int used = l2[(size_t)set * 8 + x];
+                const size_t k = (size_t)set * 8 + x;
+                if (owner[k] >= 0) {
+                    const int b = owner[k], wgs = width[b] * XW;
+                    const bool first = x == 0 || owner[k - 1] != b;
+                    if (!first) continue;                        // dealt with its first bin
+                    for (int q = 0; q < width[b]; ++q)
+                        for (int j = 0; j < XW; ++j)
+                            map[(size_t)set * RES_WGS + (size_t)j * 8 + x + q] = ResWg{b, q * XW + j, wgs, 4 * ordinal};
+                    ordinal += wgs;
+                    ++count;
+                    continue;
+                }
+                const std::vector<int>& v = bins[k];
                 int j = 0;
                 for (int b : v) {
-                    const int wgs = XW * need[b] / used;         // >= need[b]; the widths of a bin sum to <= 64
+                    const int wgs = XW * need[b] / l2[k];        // >= need[b]; the widths of a bin sum to <= 64
                     for (int r = 0; r < wgs; ++r, ++j)
                         map[(size_t)set * RES_WGS + (size_t)j * 8 + x] = ResWg{b, r, wgs, 4 * ordinal};
                     ordinal += wgs;
@@ -377,26 +428,6 @@ static int resident_deal(const Opt_Plan* p, int nb, std::vector<ResWg>* map_out,
             }
             inflight = count > inflight ? count : inflight;
         }
-    } else {
-        int groups = 4;
-        while (groups > 1 && RES_WGS / groups < mx) groups >>= 1;
-        if (forced && forced <= RES_MAX_GROUPS && (RES_WGS / forced) >= mx && (RES_WGS % forced) == 0) groups = forced;
-        const int wgs = RES_WGS / groups;
-        nsets = (nb + groups - 1) / groups;
-        map.assign((size_t)nsets * RES_WGS, idle);
-        for (int set = 0; set < nsets; ++set)
-            for (int i = 0; i < RES_WGS; ++i) {
-                // a group takes 8 / groups whole XCDs and every XCD holds a run of 64 consecutive ranks: tiles are
-                // dealt in list (row-major) order, so nearly all of a workgroup's halo neighbours share its XCD
-                // and only the workgroups next to a run boundary must publish z write-through (arap_resident.h)
-                int g, rank;
-                const int x = i & 7, j = i >> 3;
-                if (groups >= 8) { g = x + 8 * (j / wgs); rank = j % wgs; }
-                else { const int xper = 8 / groups; g = x / xper; rank = (x % xper) * XW + j; }
-                const int b = set * groups + g;
-                if (b < nb) map[(size_t)set * RES_WGS + i] = ResWg{b, rank, wgs, 4 * g * wgs};
-            }
-        inflight = nb < groups ? nb : groups;
     }
     if (map_out) map_out->swap(map);
     if (inflight_out) *inflight_out = inflight;

@@ -354,6 +354,37 @@ def test_resident_packing_of_many_uneven_solves(gpu_state):
         assert a["cost"] == b["cost"]
 
 
+def test_resident_mixed_wide_and_narrow_solves(gpu_state):
+    """One batch with solves of very different widths: a whole-frame solve (1680 tiles: four whole XCDs, two-level
+    sums), a half-frame one (two XCDs) and DAVIS-shaped ones that share the remaining XCDs.  The host packs them into
+    two launches; every result equals the two-kernel path bit for bit."""
+    from arap_flow_amd import synth
+    W, H = 854, 480
+    full = synth.make_frame(W, H, seed=40, full_mask=True)
+    half = synth.make_frame(W, H, seed=41, full_mask=True)
+    half["mask_red"] = half["mask_red"].copy()
+    half["mask_red"][:, W // 2:] = 255                           # ~840 tiles: two XCDs
+    half["constraints"] = np.asarray([c for c in half["constraints"] if c[0] < W // 2 - 2 and c[2] < W // 2 - 2], np.int32)
+    solves = [full, half] + [synth.make_frame(W, H, seed=42 + s) for s in range(5)]
+    n = len(solves)
+    sched = (1, 2, 40)
+    outs = []
+    for resident in (True, False):
+        gpu_state.set_resident(resident)
+        fs = opt.FrameSolver(gpu_state, W, H, batch=n)
+        for b, f in enumerate(solves):
+            fs.set_frame(b, f["mask_red"], f["constraints"])
+        fs.solve(n, *sched)
+        outs.append([fs.results(b, want_rgb=False) for b in range(n)])
+        st = fs.stats()
+        if resident:
+            assert st["resident_launches_per_step"] == 2 and st["resident_solves_in_flight"] >= 4, st
+        fs.close()
+    gpu_state.set_resident(True)
+    for a, b in zip(*outs):
+        assert np.array_equal(a["offset"], b["offset"]) and np.array_equal(a["angle"], b["angle"])
+
+
 def test_frame_edge_cases_empty_mask_and_no_constraints(gpu_state, oracle):
     """a frame whose mask excludes every vertex (nothing to solve, flow stays 0), a frame without any file
     constraint (only the border pins act) and a batch mixing them with a normal frame"""
