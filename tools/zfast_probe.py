@@ -1,3 +1,6 @@
+"""Diagnostic for groups that span XCDs (854x480, every vertex active): which workgroups keep their z in L2, how many
+halo neighbours / remote neighbours they see, and whether the resident path equals the two-kernel path.
+   ARAPOPT_STAMPS=1 python tools/zfast_probe.py"""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
