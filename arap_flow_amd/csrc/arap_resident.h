@@ -629,7 +629,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 }
                 const float ax = axy.x, ay = axy.y;
                 apx[j] = ax; apy[j] = ay; apa[j] = aa;
-                acc += (double)keep_if<5>(f, dot3(pv.x, pv.y, pa_, ax, ay, aa));
+                acc += (double)dot3(pv.x, pv.y, pa_, ax, ay, aa);      // an excluded lane has p = 0 and Ap = 0: no mask needed
             }
             __builtin_amdgcn_sched_barrier(0);
         }
