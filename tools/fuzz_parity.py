@@ -1,0 +1,74 @@
+"""Randomised parity sweep (GPU): random sizes, masks, constraints and batch mixes; the resident path, the two-kernel
+path and the float32 CPU oracle must agree bit for bit on short schedules.   python tools/fuzz_parity.py [N] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from arap_flow_amd import opt
+from oracle import oracle as orc
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+st = opt.State()
+
+
+def random_mask(W, H):
+    kind = rng.integers(0, 5)
+    m = np.full((H, W), 255, np.uint8)
+    if kind == 0:
+        m[:] = 0                                              # everything active (touches the border)
+    elif kind == 1:                                           # random rectangles
+        for _ in range(rng.integers(1, 5)):
+            x0, y0 = rng.integers(0, W), rng.integers(0, H)
+            m[y0:y0 + rng.integers(1, H + 1), x0:x0 + rng.integers(1, W + 1)] = 0
+    elif kind == 2:                                           # noise: isolated vertices, ragged edges
+        m[rng.random((H, W)) < rng.uniform(0.05, 0.9)] = 0
+    elif kind == 3:                                           # ellipse
+        ys, xs = np.mgrid[0:H, 0:W]
+        m[((xs - W / 2) / (W * rng.uniform(0.1, 0.6))) ** 2 + ((ys - H / 2) / (H * rng.uniform(0.1, 0.6))) ** 2 < 1] = 0
+    else:                                                     # stripes one vertex wide
+        m[::rng.integers(2, 5)] = 0
+    return m
+
+
+def random_constraints(W, H, mask):
+    n = int(rng.integers(0, 40))
+    c = []
+    for _ in range(n):
+        x, y = int(rng.integers(0, W)), int(rng.integers(0, H))
+        c.append((x, y, x + int(rng.integers(-6, 7)), y + int(rng.integers(-6, 7))))
+    return np.asarray(c, np.int32).reshape(-1, 4)
+
+
+bad = 0
+t0 = time.time()
+for it in range(N):
+    W, H = int(rng.integers(1, 330)), int(rng.integers(1, 200))
+    if rng.random() < 0.15:
+        W, H = int(rng.integers(600, 900)), int(rng.integers(300, 500))
+    nb = int(rng.integers(1, 6))
+    frames = [(random_mask(W, H), None) for _ in range(nb)]
+    frames = [(m, random_constraints(W, H, m)) for m, _ in frames]
+    sched = (int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 25)))
+    pins = bool(rng.integers(0, 2))
+    outs = []
+    for resident in (True, False):
+        st.set_resident(resident)
+        fs = opt.FrameSolver(st, W, H, batch=nb)
+        for b, (m, c) in enumerate(frames):
+            fs.set_frame(b, m, c, border_pins=pins)
+        fs.solve(nb, *sched)
+        outs.append([fs.results(b, want_rgb=False) for b in range(nb)])
+        fs.close()
+    st.set_resident(True)
+    for b, (m, c) in enumerate(frames):
+        a, t = outs[0][b], outs[1][b]
+        ok = np.array_equal(a["offset"], t["offset"]) and np.array_equal(a["angle"], t["angle"])
+        if ok and W * H <= 40000:
+            O, A, _ = orc.frame(m, c, numIter=sched[0], nIterations=sched[1], lIterations=sched[2], dtype=np.float32,
+                                mode=1, trig=1, border_pins=pins)
+            ok = np.array_equal(a["offset"], O) and np.array_equal(a["angle"], A)
+        if not ok:
+            bad += 1
+            print("MISMATCH it", it, "W,H", W, H, "nb", nb, "slot", b, "sched", sched, "pins", pins, "active", int((m == 0).sum()))
+print("fuzz: %d cases, %d mismatches, %.1f s" % (N, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
