@@ -8,6 +8,7 @@ from oracle import oracle as orc
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+LONG = len(sys.argv) > 3 and sys.argv[3] == "long"          # long schedules: (3, 3, 200)
 st = opt.State()
 
 
@@ -40,6 +41,7 @@ def random_constraints(W, H, mask):
 
 
 bad = 0
+nans = 0          # solves that blew up (unconstrained components without pins): NaN on every path alike
 t0 = time.time()
 for it in range(N):
     W, H = int(rng.integers(1, 330)), int(rng.integers(1, 200))
@@ -48,7 +50,7 @@ for it in range(N):
     nb = int(rng.integers(1, 6))
     frames = [(random_mask(W, H), None) for _ in range(nb)]
     frames = [(m, random_constraints(W, H, m)) for m, _ in frames]
-    sched = (int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 25)))
+    sched = (3, 3, 200) if LONG else (int(rng.integers(1, 3)), int(rng.integers(1, 3)), int(rng.integers(1, 25)))
     pins = bool(rng.integers(0, 2))
     outs = []
     for resident in (True, False):
@@ -62,13 +64,18 @@ for it in range(N):
     st.set_resident(True)
     for b, (m, c) in enumerate(frames):
         a, t = outs[0][b], outs[1][b]
-        ok = np.array_equal(a["offset"], t["offset"]) and np.array_equal(a["angle"], t["angle"])
+        ok = np.array_equal(a["offset"], t["offset"], equal_nan=True) and np.array_equal(a["angle"], t["angle"], equal_nan=True)
+        why = "" if ok else "resident != two-kernel (max abs %g, %d floats)" % (np.abs(a["offset"] - t["offset"]).max(), int((a["offset"] != t["offset"]).sum()))
         if ok and W * H <= 40000:
             O, A, _ = orc.frame(m, c, numIter=sched[0], nIterations=sched[1], lIterations=sched[2], dtype=np.float32,
                                 mode=1, trig=1, border_pins=pins)
-            ok = np.array_equal(a["offset"], O) and np.array_equal(a["angle"], A)
+            ok = np.array_equal(a["offset"], O, equal_nan=True) and np.array_equal(a["angle"], A, equal_nan=True)
+            if not ok:
+                why = "GPU != oracle (max abs %g, %d floats; finite %s, cost gpu %g)" % (
+                    np.nanmax(np.abs(a["offset"] - O)), int((a["offset"] != O).sum()), bool(np.isfinite(O).all() and np.isfinite(a["offset"]).all()), a["cost"])
+        nans += int(not np.isfinite(a["offset"]).all())
         if not ok:
             bad += 1
-            print("MISMATCH it", it, "W,H", W, H, "nb", nb, "slot", b, "sched", sched, "pins", pins, "active", int((m == 0).sum()))
-print("fuzz: %d cases, %d mismatches, %.1f s" % (N, bad, time.time() - t0))
+            print("MISMATCH it", it, "W,H", W, H, "nb", nb, "slot", b, "sched", sched, "pins", pins, "active", int((m == 0).sum()), why)
+print("fuzz: %d cases, %d mismatches, %d solves with non-finite results (identical on all paths), %.1f s" % (N, bad, nans, time.time() - t0))
 sys.exit(1 if bad else 0)
