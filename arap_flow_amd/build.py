@@ -61,7 +61,7 @@ def build_host(force=False, verbose=False):
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + \
               [os.path.join(HOST_DIR, f) for f in srcs] + \
               ["-o", out, "-L" + OUT_DIR, "-larapopt", "-Wl,-rpath,$ORIGIN/../lib", "-L/opt/rocm/lib", "-lamdhip64",
-               "-Wl,-rpath,/opt/rocm/lib", "-lz"]
+               "-Wl,-rpath,/opt/rocm/lib", "-lz", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

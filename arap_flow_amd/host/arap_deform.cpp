@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <future>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -133,13 +135,30 @@ int main(int argc, const char* argv[])
     // launch (ArapFlow_SolverLaunchesFor); minFill frames per call when the resident kernel does not apply.
     const unsigned maxBatch = 32, minFill = 8;
 
+    // Host work overlaps the GPU: list lines are decoded ahead by worker threads (loadData: PNGs, constraint file,
+    // border pins) and a finished batch is encoded and written by another thread while the next batch is being solved.
+    struct Loaded { bool ok = false; Frame f; };
+    const size_t kAhead = 2 * maxBatch;
+    std::vector<std::future<Loaded>> loading(lines.size());
+    std::vector<std::unique_ptr<Loaded>> loaded(lines.size());
+    size_t started = 0;
+    auto frame_at = [&](size_t k) -> Loaded& {
+        for (; started < lines.size() && started <= k + kAhead; ++started) {
+            const SolvePaths* q = &lines[started];
+            loading[started] = std::async(std::launch::async, [q]() { Loaded l; l.ok = load_frame(*q, l.f); return l; });
+        }
+        if (!loaded[k]) loaded[k].reset(new Loaded(loading[k].get()));
+        return *loaded[k];
+    };
+    struct Result { SolvePaths paths; std::vector<float> flow; std::vector<uint8_t> wrgb, wmsk; };
+    std::future<void> writer;                                            // at most one batch being written
+
     ArapFlow_Solver* solver = nullptr;
     int sw = 0, sh = 0;
     size_t i = 0;
     while (i < lines.size()) {
-        std::vector<Frame> batch(1);
-        if (!load_frame(lines[i], batch[0])) return 1;
-        const int w = batch[0].rgb.w, h = batch[0].rgb.h;
+        if (!frame_at(i).ok) return 1;
+        const int w = frame_at(i).f.rgb.w, h = frame_at(i).f.rgb.h;
         if (w != sw || h != sh) {
             if (solver) {
                 printf("Warning: Input image has different size to one in the prebuilt plan.\n"
@@ -155,33 +174,44 @@ int main(int argc, const char* argv[])
             return ArapFlow_SolverSetFrame(solver, b, f.rgb.rgb.data(), f.mask_red.data(), f.constraints.data(),
                                            (unsigned)(f.constraints.size() / 4), 0) == 0;
         };
-        if (!add_image(0, batch[0])) return 1;
-        size_t j = i + 1;
+        std::vector<SolvePaths> batch;
+        size_t j = i;
         while (j < lines.size() && batch.size() < maxBatch) {
-            Frame f;
-            if (!load_frame(lines[j], f)) return 1;
-            if (f.rgb.w != w || f.rgb.h != h) break;                     // next batch starts here (re-read then)
+            Loaded& l = frame_at(j);
+            if (!l.ok) return 1;
+            if (l.f.rgb.w != w || l.f.rgb.h != h) break;                 // next batch starts here
             const unsigned b = (unsigned)batch.size();
-            if (!add_image(b, f)) return 1;
-            const int launches = ArapFlow_SolverLaunchesFor(solver, b + 1);
-            if (launches > 1 || (launches == 0 && b >= minFill)) break;  // this frame opens the next batch
-            batch.push_back(std::move(f));
+            if (!add_image(b, l.f)) return 1;
+            if (b > 0) {
+                const int launches = ArapFlow_SolverLaunchesFor(solver, b + 1);
+                if (launches > 1 || (launches == 0 && b >= minFill)) break;   // this frame opens the next batch
+            }
+            batch.push_back(l.f.paths);
+            loaded[j].reset();                                           // the device holds it now
             ++j;
         }
         ArapFlow_SolverSolve(solver, (unsigned)batch.size(), numIter, nonLinearIter, linearIter);   // solveAll
         ArapFlow_SolverWarp(solver, (unsigned)batch.size());
-        std::vector<float> flow((size_t)w * h * 2);
-        std::vector<uint8_t> wrgb((size_t)w * h * 3), wmsk((size_t)w * h);
-        for (size_t b = 0; b < batch.size(); ++b) {
-            ArapFlow_SolverGetResults(solver, (unsigned)b, flow.data(), wrgb.data(), wmsk.data(), nullptr, nullptr, nullptr);
-            std::string err;
-            if (!arapio::write_png_rgb(batch[b].paths.warped_rgb, w, h, wrgb.data(), err)) printf("%s\n", err.c_str());
-            if (!arapio::write_png_mask1(batch[b].paths.warped_mask, w, h, wmsk.data(), err)) printf("%s\n", err.c_str());
-            arapio::write_flo(batch[b].paths.flow, flow.data(), w, h);
-            printf("Saved\n");
+        auto results = std::make_shared<std::vector<Result>>(batch.size());
+        for (size_t b = 0; b < batch.size(); ++b) {                      // copyResultToCPU (blocks until the GPU is done)
+            Result& r = (*results)[b];
+            r.paths = batch[b];
+            r.flow.resize((size_t)w * h * 2); r.wrgb.resize((size_t)w * h * 3); r.wmsk.resize((size_t)w * h);
+            ArapFlow_SolverGetResults(solver, (unsigned)b, r.flow.data(), r.wrgb.data(), r.wmsk.data(), nullptr, nullptr, nullptr);
         }
+        if (writer.valid()) writer.get();
+        writer = std::async(std::launch::async, [results, w, h]() {
+            for (const Result& r : *results) {
+                std::string err;
+                if (!arapio::write_png_rgb(r.paths.warped_rgb, w, h, r.wrgb.data(), err)) printf("%s\n", err.c_str());
+                if (!arapio::write_png_mask1(r.paths.warped_mask, w, h, r.wmsk.data(), err)) printf("%s\n", err.c_str());
+                arapio::write_flo(r.paths.flow, r.flow.data(), w, h);
+                printf("Saved\n");
+            }
+        });
         i = j;
     }
+    if (writer.valid()) writer.get();
     if (solver) ArapFlow_SolverFree(solver);
     ArapFlow_FreeState(state);
     return 0;

@@ -62,57 +62,84 @@ def save_mask(mask, path):
 FILL_MIN, FILL_MAX = 8, 32     # frames per solve call: at least / at most (see deform_list)
 
 
+def _load_line(ln):
+    """loadData (main.cpp:116-138) of one list line: RGB, red channel of the mask, constraint rows"""
+    from . import opt
+    return load_rgb(ln[0]), load_mask_red(ln[1]), opt.load_constraints(ln[2])
+
+
+def _save_result(ln, r):
+    Image.fromarray(r["warped_rgb"]).save(ln[4])
+    save_mask(r["warped_mask"], ln[5])
+    flo.flow_write(ln[3], r["flow"])
+
+
 def deform_list(state, lines, num_iter=19, non_linear_iter=8, linear_iter=400, max_batch=FILL_MAX, verbose=True):
     """arap_deform over a list (main.cpp:223-238).  Frames of equal size are solved together: the library gives
     every solve a group of the resident launch's workgroups sized by its active tiles, and a launch costs the same
     however full it is, so frames are added to a batch while they still fit ONE launch (8 DAVIS-shaped 854x480
-    frames, ~21 --multseg segment solves); FILL_MIN frames per call when the resident path does not apply."""
+    frames, ~21 --multseg segment solves); FILL_MIN frames per call when the resident path does not apply.
+    Host work overlaps the GPU: list lines are decoded ahead by worker threads and a finished batch is encoded and
+    written while the next one is being solved."""
+    from concurrent.futures import ThreadPoolExecutor
     from . import opt
-    i = 0
-    solver, size = None, None
-    while i < len(lines):
-        rgb0 = load_rgb(lines[i][0])
-        H, W = rgb0.shape[:2]
-        if size != (W, H):
-            if solver is not None:
-                if verbose:
-                    print("Warning: Input image has different size to one in the prebuilt plan.\n"
-                          "To avoid re-building the plan and to save time, put images of the same size in the "
-                          "same list.\nStarting to re-build plan...")      # CombinedSolver.h:151-153
-                solver.close()
-            solver = opt.FrameSolver(state, W, H, batch=max_batch)
-            size = (W, H)
-        batch = []
-        j = i
-        while j < len(lines) and len(batch) < max_batch:
-            ln = lines[j]
-            rgb = rgb0 if j == i else load_rgb(ln[0])
-            if rgb.shape[:2] != (H, W):
-                break
-            mask = load_mask_red(ln[1])
-            if mask.shape != (H, W):
-                raise ValueError("mask %s has another size than %s" % (ln[1], ln[0]))
-            cons = opt.load_constraints(ln[2])
-            b = len(batch)
-            solver.set_frame(b, mask, cons, rgb=rgb, border_pins=True)
-            if b > 0:
-                launches = solver.launches_for(b + 1)
-                if launches > 1 or (launches == 0 and b >= FILL_MIN):
-                    break                                   # this frame opens the next batch (its slot is re-set)
-            batch.append(ln)
-            j += 1
-        solver.solve(len(batch), num_iter, non_linear_iter, linear_iter)
-        solver.warp(len(batch))
-        for b, ln in enumerate(batch):
-            r = solver.results(b)
-            Image.fromarray(r["warped_rgb"]).save(ln[4])
-            save_mask(r["warped_mask"], ln[5])
-            flo.flow_write(ln[3], r["flow"])
+    ahead = 2 * max_batch
+    with ThreadPoolExecutor(max_workers=8) as pool:
+        loading = {}
+
+        def frame_at(k):
+            for q in range(k, min(len(lines), k + ahead + 1)):
+                if q not in loading:
+                    loading[q] = pool.submit(_load_line, lines[q])
+            return loading[k].result()
+
+        writing = []
+        i = 0
+        solver, size = None, None
+        while i < len(lines):
+            rgb0 = frame_at(i)[0]
+            H, W = rgb0.shape[:2]
+            if size != (W, H):
+                if solver is not None:
+                    if verbose:
+                        print("Warning: Input image has different size to one in the prebuilt plan.\n"
+                              "To avoid re-building the plan and to save time, put images of the same size in the "
+                              "same list.\nStarting to re-build plan...")      # CombinedSolver.h:151-153
+                    solver.close()
+                solver = opt.FrameSolver(state, W, H, batch=max_batch)
+                size = (W, H)
+            batch = []
+            j = i
+            while j < len(lines) and len(batch) < max_batch:
+                ln = lines[j]
+                rgb, mask, cons = frame_at(j)
+                if rgb.shape[:2] != (H, W):
+                    break
+                if mask.shape != (H, W):
+                    raise ValueError("mask %s has another size than %s" % (ln[1], ln[0]))
+                b = len(batch)
+                solver.set_frame(b, mask, cons, rgb=rgb, border_pins=True)
+                if b > 0:
+                    launches = solver.launches_for(b + 1)
+                    if launches > 1 or (launches == 0 and b >= FILL_MIN):
+                        break                                   # this frame opens the next batch (its slot is re-set)
+                batch.append(ln)
+                del loading[j]                                  # the device holds it now
+                j += 1
+            solver.solve(len(batch), num_iter, non_linear_iter, linear_iter)
+            solver.warp(len(batch))
+            results = [solver.results(b) for b in range(len(batch))]      # blocks until the GPU is done
+            for f in writing:
+                f.result()
+            writing = [pool.submit(_save_result, ln, r) for ln, r in zip(batch, results)]
             if verbose:
-                print("Saved")                                              # main.cpp:159
-        i = j
-    if solver is not None:
-        solver.close()
+                for _ in batch:
+                    print("Saved")                                          # main.cpp:159
+            i = j
+        for f in writing:
+            f.result()
+        if solver is not None:
+            solver.close()
 
 
 def warp_files(state, rgb_path, mask_path, flo_path, out_rgb_path, out_mask_path):
