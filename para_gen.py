@@ -11,7 +11,8 @@ child process per GPU, HIP_VISIBLE_DEVICES per child, no collective), flatten se
 background into the warped frame, write OUT/all_files.list.
 
 Differences from the reference, all at its edges:
-  * --arap_bin defaults to this repo's arap_deform.py (MI355X); any executable with the same argv works.
+  * --arap_bin defaults to this repo's C++ driver arap_flow_amd/bin/arap_deform (arap_deform.py if it is not built);
+    any executable with the same argv works.  --narap defaults to 32 (reference: 7): see its comment.
   * DeepMatching (para_gen.py:227-240) is an external binary that is not part of the reference tree.  Either
     pass --dm_bin (called exactly as the reference does) or --matches DIR holding precomputed
     `x1 y1 x2 y2 ...` lines at DIR/<seq>/<frame>.txt.
@@ -244,12 +245,16 @@ def parse(argv=None):
                         help="if each object segment is treated separately")
     parser.add_argument("--resume", action="store_true", default=False,
                         help="To skip the images that have *.flo finished.")
-    parser.add_argument("--narap", type=int, default=7, help="Number of buffered files to be run by ARAP on gpu")
+    # (reference default: 7.  A child here costs ~0.4 s to start and solves 8 854x480 frames per 0.4 s launch, so
+    #  larger hand-outs keep the GPUs busy; any value works.)
+    parser.add_argument("--narap", type=int, default=32, help="Number of buffered files to be run by ARAP on gpu")
     parser.add_argument("--size", nargs=2, default=None,
                         help="2-tuple of [width] [space] [height] to which all images are resized.")
     parser.add_argument("--fd", type=int, default=1, help="distance between the 2 frames, default=1")
-    parser.add_argument("--arap_bin", default="%s %s" % (sys.executable, osp.join(HERE, "arap_deform.py")),
-                        help="ARAP executable (argv contract of arap_deform), default: this repo's arap_deform.py")
+    cpp_bin = osp.join(HERE, "arap_flow_amd", "bin", "arap_deform")
+    parser.add_argument("--arap_bin", default=cpp_bin if osp.exists(cpp_bin) else "%s %s" % (sys.executable, osp.join(HERE, "arap_deform.py")),
+                        help="ARAP executable (argv contract of arap_deform), default: this repo's C++ driver "
+                             "arap_flow_amd/bin/arap_deform when it is built, else arap_deform.py")
     parser.add_argument("--dm_bin", default=None, help="Path to the deep matching binary")
     parser.add_argument("--matches", default=None, help="directory of precomputed matches (instead of --dm_bin)")
     parser.add_argument("--bg_dir", default=None, help="directory of background images")
