@@ -199,7 +199,7 @@ def main():
         if not a.no_kernel_timing:
             tl = min(lIter, 400)
             st.set_kernel_timing(True)
-            fs.solve(S, 1, 2, tl)                      # 2 Gauss-Newton steps of tl PCG iterations
+            fs.solve(S, 1, 4, tl)                      # 4 Gauss-Newton steps of tl PCG iterations
             torch.cuda.synchronize()
             kt = {k: st.kernel_time(k) for k in ("PCGResident", "PCGStepA", "PCGStepB")}
             st.set_kernel_timing(False)
@@ -208,9 +208,9 @@ def main():
                 tot_ms, n = kt["PCGResident"]
                 # one launch = all `tl` PCG iterations of one GN step for the frames in flight;
                 # algorithmic bytes: 160 B per active vertex per PCG iteration
-                bytes_total = 160.0 * n_act_total * tl * 2
+                bytes_total = 160.0 * n_act_total * tl * 4
                 ach = bytes_total / (tot_ms * 1e-3) / 1e9
-                frames_per_launch = S * 2.0 / n
+                frames_per_launch = S * 4.0 / n
                 out["roofline"] = {
                     "bound": "hbm", "kernel": "k_pcg_resident", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": tot_ms / n * 1e3, "launches": n,
