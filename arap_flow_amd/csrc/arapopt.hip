@@ -311,13 +311,13 @@ static bool plan_resident_eligible(const Opt_Plan* p)
 //    the workgroups next to a run boundary publish z write-through and the group's sums are gathered in two levels
 //    (arap_resident.h).
 // Returns the number of launches; fills `map` ([launches][RES_WGS]) and `inflight_out` when given.
-static int resident_deal(const Opt_Plan* p, int nb, std::vector<ResWg>* map_out, int* inflight_out)
+static int resident_deal(const int* ntiles, int nb, std::vector<ResWg>* map_out, int* inflight_out)
 {
     const int XW = RES_WGS / 8;                                  // workgroups per XCD
     std::vector<int> need(nb), width(nb);
     int mx = 1;
     for (int b = 0; b < nb; ++b) {
-        need[b] = (p->h_ntiles[b] + RES_TILES_PER_WG - 1) / RES_TILES_PER_WG;
+        need[b] = (ntiles[b] + RES_TILES_PER_WG - 1) / RES_TILES_PER_WG;
         if (need[b] < 1) need[b] = 1;
         mx = need[b] > mx ? need[b] : mx;
         width[b] = 1;                                            // bins taken: 1 (shared) or 2, 4, 8 (whole)
@@ -438,7 +438,7 @@ static int resident_deal(const Opt_Plan* p, int nb, std::vector<ResWg>* map_out,
 static bool plan_resident_pack(Opt_Plan* p)
 {
     std::vector<ResWg> map;
-    const int nsets = resident_deal(p, p->nb, &map, &p->res_inflight);
+    const int nsets = resident_deal(p->h_ntiles.data(), p->nb, &map, &p->res_inflight);
     const bool same = nsets == p->res_sets && map.size() == p->h_wgmap.size() &&
                       memcmp(map.data(), p->h_wgmap.data(), map.size() * sizeof(ResWg)) == 0;
     if (same) return false;
@@ -1413,8 +1413,22 @@ int ArapFlow_SolverLaunchesFor(ArapFlow_Solver* s, unsigned nframes)
     Opt_Plan* p = s->plan;
     const int keep = p->nb;
     p->nb = (int)nframes;                              // eligibility looks at the first nb slots
-    const int sets = plan_resident_eligible(p) ? resident_deal(p, (int)nframes, nullptr, nullptr) : 0;
+    const int sets = plan_resident_eligible(p) ? resident_deal(p->h_ntiles.data(), (int)nframes, nullptr, nullptr) : 0;
     p->nb = keep;
+    return sets;
+}
+int ArapFlow_ResidentDeal(const int* active_tiles, unsigned nsolves, int* table, unsigned table_launches)
+{
+    if (!active_tiles || nsolves == 0) return -1;
+    for (unsigned b = 0; b < nsolves; ++b)
+        if (active_tiles[b] < 0 || active_tiles[b] > RES_MAX_TILES) return -1;
+    std::vector<ResWg> map;
+    const int sets = resident_deal(active_tiles, (int)nsolves, &map, nullptr);
+    if (table)
+        for (size_t i = 0; i < map.size() && i < (size_t)table_launches * RES_WGS; ++i) {
+            table[4 * i + 0] = map[i].slot; table[4 * i + 1] = map[i].rank;
+            table[4 * i + 2] = map[i].wgs; table[4 * i + 3] = map[i].gran;
+        }
     return sets;
 }
 int ArapFlow_SolverResidentLayout(ArapFlow_Solver* s, int* launches_per_step, int* solves_in_flight)

@@ -197,6 +197,11 @@ int ArapFlow_SolverResidentLayout(ArapFlow_Solver* s, int* launches_per_step, in
  * (0: the two-kernel path would run, -1: bad arguments).  Every launch costs about the same time however full it
  * is, so a host that wants the best throughput adds frames to a batch while this stays 1 (arap_deform does). */
 int ArapFlow_SolverLaunchesFor(ArapFlow_Solver* s, unsigned nframes);
+/* The deal itself, as a pure host function (no device needed): given the active 64x4-tile counts of `nsolves` solves
+ * (each <= 4608) it returns the number of resident launches and, when `table` is given, writes for each of the first
+ * `table_launches` launches the 512 workgroup entries {solve or -1, rank in its group, group size, granule offset}
+ * (int[table_launches][512][4]).  -1 on bad arguments. */
+int ArapFlow_ResidentDeal(const int* active_tiles, unsigned nsolves, int* table, unsigned table_launches);
 /* The drop-in path (Opt_ProblemInit/Step/Solve) takes the resident kernel too when, at Init, the caller's
  * UrShape is the pixel grid on every active vertex (what the application passes, CombinedSolver.h:207-221) and
  * the active tiles fit; the Mask/UrShape buffers analysed at Init must then stay the ones passed to the Steps

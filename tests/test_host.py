@@ -80,3 +80,81 @@ def test_synth_frames():
     full = synth.make_frame(64, 48, seed=1, full_mask=True)
     assert np.all(full["mask_red"] == 0)
     assert np.array_equal(synth.make_frame(64, 48, seed=5)["mask_red"], synth.make_frame(64, 48, seed=5)["mask_red"])
+
+
+def _deal(tiles):
+    """ArapFlow_ResidentDeal (pure host function of the library): launches and the [launches][512][4] table"""
+    from arap_flow_amd import build
+    lib = ctypes.CDLL(build.build())
+    lib.ArapFlow_ResidentDeal.restype = ctypes.c_int
+    t = np.ascontiguousarray(tiles, np.int32)
+    n = lib.ArapFlow_ResidentDeal(t.ctypes.data_as(ctypes.c_void_p), len(t), None, 0)
+    assert n >= 1
+    tab = np.full((n, 512, 4), -7, np.int32)
+    assert lib.ArapFlow_ResidentDeal(t.ctypes.data_as(ctypes.c_void_p), len(t), tab.ctypes.data_as(ctypes.c_void_p), n) == n
+    return n, tab
+
+
+def _check_deal(tiles, n, tab):
+    """every solve appears in exactly one launch with one contiguous rank range 0..wgs-1, enough workgroups for its
+    tiles (<= 9 each), granule blocks that do not overlap; a group of <= 64 workgroups sits on one XCD slot
+    (blockIdx & 7), a wider one on 2/4/8 whole aligned slots with ranks 64 q + j on its q-th slot"""
+    seen = {}
+    for s in range(n):
+        slot, rank, wgs, gran = tab[s, :, 0], tab[s, :, 1], tab[s, :, 2], tab[s, :, 3]
+        used = slot >= 0
+        assert int(wgs[used].sum() // 1) >= 0
+        gran_used = np.zeros(2 * 512 * 2 + 1, bool)
+        for b in np.unique(slot[used]):
+            assert b not in seen, "solve dealt twice"
+            seen[int(b)] = s
+            idx = np.nonzero(slot == b)[0]
+            w = int(wgs[idx[0]])
+            assert (wgs[idx] == w).all() and len(idx) == w and sorted(rank[idx].tolist()) == list(range(w))
+            assert w * 9 >= max(int(tiles[b]), 1)
+            g = int(gran[idx[0]])
+            assert (gran[idx] == g).all() and g % 4 == 0 and not gran_used[g:g + 4 * w].any()
+            gran_used[g:g + 4 * w] = True
+            xs = idx & 7
+            if w <= 64:
+                assert len(set(xs.tolist())) == 1
+            else:
+                k = w // 64
+                assert w % 64 == 0 and k in (2, 4, 8)
+                a = int(xs.min())
+                assert a % k == 0 and set(xs.tolist()) == set(range(a, a + k))
+                assert ((rank[idx] >> 6) == (xs - a)).all() and ((rank[idx] & 63) == (idx >> 3)).all()
+    assert sorted(seen) == list(range(len(tiles)))
+
+
+def test_resident_deal_packs_narrow_and_wide_solves():
+    """host logic of the resident path (no GPU): how solves are dealt to launches and workgroups"""
+    rng = np.random.default_rng(0)
+    # the benchmark shapes: 8 DAVIS frames -> one launch, one per XCD; 21 segments -> one launch; full frames -> two per launch
+    n, tab = _deal([490] * 8)
+    assert n == 1 and sorted(set((np.nonzero(tab[0, :, 0] == b)[0] & 7).tolist()).pop() for b in range(8)) == list(range(8))
+    assert (tab[0, :, 2][tab[0, :, 0] >= 0] == 64).all()                  # widened to the whole XCD
+    _check_deal([490] * 8, n, tab)
+    n, tab = _deal([185] * 21)                                             # 21 workgroups each: three per XCD
+    assert n == 1
+    _check_deal([185] * 21, n, tab)
+    n, tab = _deal([1680, 1680, 1680])
+    assert n == 2
+    _check_deal([1680, 1680, 1680], n, tab)
+    n, tab = _deal([1680, 840, 500, 500, 500, 500, 500])                   # width 4 + width 2 + narrow ones
+    assert n == 2
+    _check_deal([1680, 840, 500, 500, 500, 500, 500], n, tab)
+    n, tab = _deal([4608])                                                 # the largest solve: all 512 workgroups
+    assert n == 1 and (tab[0, :, 2] == 512).all()
+    _check_deal([4608], n, tab)
+    n, tab = _deal([0, 1, 9, 10])                                          # empty and tiny solves still get a group
+    _check_deal([0, 1, 9, 10], n, tab)
+    for _ in range(200):                                                   # random mixes
+        k = int(rng.integers(1, 40))
+        tiles = rng.choice([0, 3, 40, 150, 200, 480, 577, 900, 1200, 2400, 4608], size=k).astype(np.int32)
+        tiles = np.where(rng.random(k) < 0.5, rng.integers(0, 600, k), tiles).astype(np.int32)
+        n, tab = _deal(tiles)
+        _check_deal(tiles, n, tab)
+        need = np.maximum((tiles + 8) // 9, 1)
+        assert n >= int(np.ceil(need.sum() / 512))                         # cannot beat the capacity bound ...
+        assert n <= len(tiles)                                             # ... and never worse than one solve per launch
