@@ -12,7 +12,7 @@ background into the warped frame, write OUT/all_files.list.
 
 Differences from the reference, all at its edges:
   * --arap_bin defaults to this repo's C++ driver arap_flow_amd/bin/arap_deform (arap_deform.py if it is not built);
-    any executable with the same argv works.  --narap defaults to 32 (reference: 7): see its comment.
+    any executable with the same argv works.  --narap defaults to 64 (reference: 7): see its comment.
   * DeepMatching (para_gen.py:227-240) is an external binary that is not part of the reference tree.  Either
     pass --dm_bin (called exactly as the reference does) or --matches DIR holding precomputed
     `x1 y1 x2 y2 ...` lines at DIR/<seq>/<frame>.txt.
@@ -247,7 +247,7 @@ def parse(argv=None):
                         help="To skip the images that have *.flo finished.")
     # (reference default: 7.  A child here costs ~0.4 s to start and solves 8 854x480 frames per 0.4 s launch, so
     #  larger hand-outs keep the GPUs busy; any value works.)
-    parser.add_argument("--narap", type=int, default=32, help="Number of buffered files to be run by ARAP on gpu")
+    parser.add_argument("--narap", type=int, default=64, help="Number of buffered files to be run by ARAP on gpu")
     parser.add_argument("--size", nargs=2, default=None,
                         help="2-tuple of [width] [space] [height] to which all images are resized.")
     parser.add_argument("--fd", type=int, default=1, help="distance between the 2 frames, default=1")
