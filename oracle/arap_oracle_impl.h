@@ -28,7 +28,14 @@
 #define CAT(a, b) CAT_(a, b)
 #define FN(name) CAT(name, SUF)
 /* fused multiply-add a*b + c with ONE rounding, at exactly the sites the HIP kernels fuse */
+#undef FMA
+/* -DORACLE_NO_FMA (liboracle_nofma.so): the same sites as separate multiply and add, two roundings -- one of the
+ * arithmetic variants of tests/golden/make_t4_variants.py (how far does fusing move the unconverged 19/8/400 answer) */
+#ifdef ORACLE_NO_FMA
+#define FMA(a, b, c) ((REAL)((REAL)(a) * (REAL)(b)) + (REAL)(c))
+#else
 #define FMA(a, b, c) (sizeof(REAL) == 4 ? (REAL)fmaf((float)(a), (float)(b), (float)(c)) : (REAL)fma((double)(a), (double)(b), (double)(c)))
+#endif
 
 /* reduction mode for the three PCG dot products and the cost:
  *   0 : accumulate in REAL, sequentially in index order (one fixed instance of the order the

@@ -30,6 +30,18 @@ def lib():
     return _LIB
 
 
+def use_variant(name=None):
+    """Switch the loaded library: None = liboracle.so (the HIP path's bit-level twin), "nofma" = the same code with
+    every fused multiply-add split into multiply + add (T4 calibration only)."""
+    global _LIB
+    if name is None:
+        _LIB = None
+        return lib()
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle_%s.so" % name])
+    _LIB = C.CDLL(os.path.join(_HERE, "liboracle_%s.so" % name))
+    return _LIB
+
+
 def ref_warp_binary():
     p = os.path.join(_HERE, "_ref", "warp_image")
     return p if os.path.exists(p) else None
