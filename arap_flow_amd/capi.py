@@ -32,6 +32,7 @@ SYMBOLS = [
     ("ArapFlow_Version", C.c_char_p, []),
     ("ArapFlow_FreeState", None, [_VP]),
     ("ArapFlow_SetStream", None, [_VP, _VP]),
+    ("ArapFlow_UseOwnStream", _I, [_VP]),
     ("ArapFlow_TimerBegin", None, [_VP]),
     ("ArapFlow_TimerEnd", C.c_float, [_VP]),
     ("ArapFlow_SetKernelTiming", None, [_VP, _I]),
@@ -43,6 +44,9 @@ SYMBOLS = [
     ("ArapFlow_SolverFree", None, [_VP]),
     ("ArapFlow_SolverSetFrame", _I, [_VP, _U, _VP, _VP, _VP, _U, _I]),
     ("ArapFlow_SolverSolve", _I, [_VP, _U, _U, _U, _U]),
+    ("ArapFlow_SolverSolveAsync", _I, [_VP, _U, _U, _U, _U, _I, _I]),
+    ("ArapFlow_SolverWait", _I, [_VP]),
+    ("ArapFlow_SolverHostResults", _I, [_VP, _U, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     ("ArapFlow_SolverWarp", _I, [_VP, _U]),
     ("ArapFlow_SolverGetResults", _I, [_VP, _U, _VP, _VP, _VP, _VP, _VP, C.POINTER(C.c_double)]),
     ("ArapFlow_SolverStats", _I, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -77,6 +77,8 @@ struct ResDev {
     const ResWg* wgmap;         // [RES_WGS] of this launch
     int allow_fast;             // 0: always use the write-through (placement independent) store flavour
     int force_fail;             // test hook (ARAPOPT_FORCE_RES_FAIL=1): behave as if a group wait had timed out
+    int nowait;                 // diagnostic (ARAPOPT_RES_NOWAIT=1): one sweep per group wait, whatever the tags say (results are garbage:
+                                // measures the iteration without the waits, tools/res_stamps.py)
     unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][8] summed s_memrealtime ticks
 };
 
@@ -137,7 +139,7 @@ __device__ __forceinline__ float ld_sc1_f(const float* p)
 // Returns the sum rounded to float in every thread; false on timeout.
 __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned long long* gran_group, int rank,
                                           int wgs, float* bcast /* LDS, 2 floats */, unsigned* err, float& out,
-                                          bool fast = false, double* out_d = nullptr)
+                                          bool fast = false, double* out_d = nullptr, bool nowait = false)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
@@ -168,7 +170,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
                 mine_ok = mine_ok && (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
                 v += __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
             }
-            ok = __all(mine_ok);
+            ok = __all(mine_ok) || nowait;
             if (ok) break;
             __builtin_amdgcn_s_sleep(1);
         }
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         float sigma;
         RES_STAMP(tA);
         alive = hier ? group_sum_h(block_sum8(acc, wsum), 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
-                     : group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast);
+                     : group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast, nullptr, rd.nowait != 0);
         if (!alive) break;
         RES_STAMP(tS1);
         // ---------------- phase B: alpha, r, z, rho', delta ---------------------------------------------
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         RES_STAMP(tB);
         // (every storing wave drains inside block_sum8, before the workgroup barrier: R1)
         alive = hier ? group_sum_h(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
-                     : group_sum(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast);
+                     : group_sum(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast, nullptr, rd.nowait != 0);
         if (!alive) break;
         RES_STAMP(tS2);
         float beta = 0.f;

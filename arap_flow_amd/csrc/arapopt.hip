@@ -80,11 +80,15 @@ struct Opt_State {
     int device = 0;
     hipStream_t stream = nullptr;     // where all work is enqueued (NULL = null stream)
     hipStream_t cap = nullptr;        // private stream used only for graph capture
+    hipStream_t own_stream = nullptr; // ArapFlow_UseOwnStream
     hipEvent_t t0 = nullptr, t1 = nullptr;
     KernelTimer ktimer;
     bool use_graph = true;
     bool use_resident = true;   // ArapFlow_SetResident
-    bool resident_failed = false;   // a resident launch timed out once (GPU shared with another process?): path switched off
+    bool resident_failed = false;   // a resident launch has timed out at least once (GPU shared with another process?)
+    // After a timeout the resident path pauses for `res_cooldown` solve calls (ArapFlow_SolverSolve / Opt_ProblemInit),
+    // then it is tried again; every further timeout doubles the pause (8, 16, ... 1024), a checked success resets it.
+    int res_cooldown = 0, res_backoff = 8;
     int tile = -1;              // ArapFlow_SetTile: phase-A variant of the two-kernel path; -1 = choose per solve
 };
 
@@ -126,6 +130,10 @@ struct Opt_Plan {
     ResDev rd{};
     void* res_block = nullptr;
     std::vector<int> h_ntiles;
+    std::vector<std::vector<int>> h_tiles;   // what rd.tilelist holds per slot (skip the upload when nothing changed)
+    std::vector<uint8_t> h_tiles_valid;
+    std::vector<std::vector<int>> h_tilepos;
+    bool hole_pending = false;      // test hook ARAPOPT_FORCE_RES_FAIL=2: the next table upload leaves one workgroup out
     ResWg* d_wgmap = nullptr;       // [batch][RES_WGS]: one table per resident launch of a GN step
     std::vector<ResWg> h_wgmap;     // what d_wgmap holds
     int res_sets = 0;               // resident launches per GN step
@@ -183,6 +191,9 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     pd.red = nullptr; pd.costred = nullptr; pd.nslots = 0; pd.ncost = 0;
     p->hslots.assign(batch, Slot{});
     p->h_ntiles.assign(batch, 0);
+    p->h_tiles.assign(batch, std::vector<int>());
+    p->h_tiles_valid.assign(batch, 0);
+    p->h_tilepos.assign(batch, std::vector<int>());
     return p;
 }
 
@@ -222,10 +233,17 @@ static void plan_enable_resident(Opt_Plan* p)
     {
         const char* ff = getenv("ARAPOPT_FORCE_RES_FAIL");      // test hook
         p->rd.force_fail = (ff && ff[0] == '1') ? 1 : 0;
+        // '2': ONE real timeout -- the first table upload of this plan leaves a workgroup of the first group out, so the
+        // rest of that group spins in its first group wait until the bounded spin gives up (arap_resident.h: group_sum)
+        p->hole_pending = ff && ff[0] == '2';
     }
     {
         const char* nf = getenv("ARAPOPT_NO_XCD_FAST");
         p->rd.allow_fast = (nf && nf[0] == '1') ? 0 : 1;
+    }
+    {
+        const char* nw = getenv("ARAPOPT_RES_NOWAIT");          // diagnostic: iteration time without the group waits
+        p->rd.nowait = (nw && nw[0] == '1') ? 1 : 0;
     }
     const char* sd = getenv("ARAPOPT_STAMPS");      // diagnostic build of the resident kernel (tools/res_stamps.py)
     if (sd && sd[0] == '1') {
@@ -237,28 +255,36 @@ static void plan_enable_resident(Opt_Plan* p)
     p->res_capable = true;
 }
 
-// active-tile list of one slot (ascending tile indices), its length and the inverse map tile -> position
-static void plan_upload_tiles(Opt_Plan* p, int slot, const std::vector<int>& tiles)
+// active-tile list of one slot (ascending tile indices), its length and the inverse map tile -> position.
+// Enqueued on `cs` (the caller orders it before the kernels that read the lists and after those that still use the
+// old ones).  The sources are plan-owned host vectors that live until the next upload of the slot.
+static void plan_upload_tiles(Opt_Plan* p, int slot, const std::vector<int>& tiles, hipStream_t cs)
 {
     const int nt = (int)tiles.size();
     const int nt_all = p->pd.tilesX * p->pd.tilesY;
     p->h_ntiles[slot] = nt;
     if (!p->res_capable) return;
-    HC(hipStreamSynchronize(p->st->stream));
+    if (p->h_tiles_valid[slot] && p->h_tiles[slot] == tiles) return;      // the device already holds this list
+    p->h_tiles[slot] = tiles;
+    p->h_tiles_valid[slot] = 1;
     if (nt <= RES_MAX_TILES) {
-        std::vector<int> pos(nt_all, -1);
+        std::vector<int>& pos = p->h_tilepos[slot];
+        pos.assign(nt_all, -1);
         for (int i = 0; i < nt; ++i) pos[tiles[i]] = i;
         if (nt > 0)
-            HC(hipMemcpy((void*)(p->rd.tilelist + (size_t)slot * RES_MAX_TILES), tiles.data(), sizeof(int) * nt,
-                         hipMemcpyHostToDevice));
-        HC(hipMemcpy((void*)(p->rd.tilepos + (size_t)slot * nt_all), pos.data(), sizeof(int) * nt_all,
-                     hipMemcpyHostToDevice));
+            HC(hipMemcpyAsync((void*)(p->rd.tilelist + (size_t)slot * RES_MAX_TILES), p->h_tiles[slot].data(),
+                              sizeof(int) * nt, hipMemcpyHostToDevice, cs));
+        HC(hipMemcpyAsync((void*)(p->rd.tilepos + (size_t)slot * nt_all), pos.data(), sizeof(int) * nt_all,
+                          hipMemcpyHostToDevice, cs));
     }
-    HC(hipMemcpy((void*)(p->rd.ntiles + slot), &nt, sizeof(int), hipMemcpyHostToDevice));
+    HC(hipMemcpyAsync((void*)(p->rd.ntiles + slot), &p->h_ntiles[slot], sizeof(int), hipMemcpyHostToDevice, cs));
 }
 
-// Opt_ProblemInit: look at the caller's Mask and UrShape once (the reference's init also blocks on a device
-// read-back, solverGPUGaussNewton.t:1006,790-797) to decide whether the Steps can take the resident kernel.
+// Opt_ProblemInit and every Opt_ProblemStep of a drop-in plan: look at the caller's Mask and UrShape (one small
+// kernel + a read-back of one byte per tile; the reference's init and step block on a device read-back too,
+// solverGPUGaussNewton.t:1006,1117,790-797) to decide whether the step can take the resident kernel and with which
+// active-tile list.  The reference re-reads every parameter at every Step (:960,1026) and lets the caller change
+// them in between (Opt.h:58-66): so does this -- new Mask / UrShape contents or swapped buffers are seen here.
 static void plan_analyse_for_resident(Opt_Plan* p)
 {
     p->opt_res_ok = false;
@@ -278,8 +304,8 @@ static void plan_analyse_for_resident(Opt_Plan* p)
         if (act[t]) tiles.push_back(t);
     const int nt = (int)tiles.size();
     p->h_ntiles[0] = nt;                        // also steers the automatic phase-A variant of the two-kernel path
-    if (notgrid || !p->res_capable || !st->use_resident || nt > RES_MAX_TILES) return;
-    plan_upload_tiles(p, 0, tiles);
+    if (notgrid || !p->res_capable || !st->use_resident || st->res_cooldown > 0 || nt > RES_MAX_TILES) return;
+    plan_upload_tiles(p, 0, tiles, st->stream);
     p->opt_res_ok = true;
     p->opt_res_slot = p->hslots[0];
 }
@@ -287,9 +313,9 @@ static void plan_analyse_for_resident(Opt_Plan* p)
 static bool plan_resident_eligible(const Opt_Plan* p)
 {
     if (!p->res_capable || !p->st->use_resident) return false;
+    if (p->st->res_cooldown > 0) return false;          // pausing after a timed-out launch (plan_resident_failed)
     if (!p->res_frames) {
-        // drop-in plan: only with the images that were analysed at Init (the caller may swap buffers between
-        // Steps, solverGPUGaussNewton.t:1026; then the general two-kernel path runs)
+        // drop-in plan: only with the images analysed just before this step (plan_analyse_for_resident)
         const Slot& a = p->opt_res_slot;
         const Slot& c = p->hslots[0];
         if (!p->opt_res_ok || a.M != c.M || a.U != c.U) return false;
@@ -455,14 +481,19 @@ static bool plan_resident_failed(Opt_Plan* p)
 {
     if (!p->res_capable || p->res_launches == 0) return false;
     unsigned e = 0;
-    HC(hipMemcpy(&e, p->rd.err, sizeof(e), hipMemcpyDeviceToHost));
+    HC(hipMemcpyAsync(&e, p->rd.err, sizeof(e), hipMemcpyDeviceToHost, p->st->stream));
+    HC(hipStreamSynchronize(p->st->stream));
     if (e == 0) return false;
-    if (!p->st->resident_failed)
-        fprintf(stderr, "arapopt: resident PCG kernel gave up at a group wait (code 0x%08x); is the GPU shared? "
-                        "Falling back to the two-kernel path for this state.\n", e);
-    p->st->resident_failed = true;
-    p->st->use_resident = false;
-    HC(hipMemset((void*)p->rd.err, 0, sizeof(unsigned)));
+    Opt_State* st = p->st;
+    fprintf(stderr, "arapopt: resident PCG kernel gave up at a group wait (code 0x%08x); is the GPU shared? "
+                    "Falling back to the two-kernel path for the next %d solve calls.\n", e, st->res_backoff);
+    st->resident_failed = true;
+    st->res_cooldown = st->res_backoff;
+    st->res_backoff = st->res_backoff >= 1024 ? 1024 : 2 * st->res_backoff;
+    HC(hipMemsetAsync((void*)p->rd.err, 0, sizeof(unsigned), st->stream));
+    HC(hipStreamSynchronize(st->stream));
+    p->h_wgmap.clear();                     // (the test hook's table with a hole must not survive: re-deal next time)
+    p->res_sets = 0;
     return true;
 }
 
@@ -623,7 +654,6 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
             else
                 LAUNCH_DYN(p, s, "PCGResident", k_pcg_resident<false>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES,
                            p->pd, rd, L);
-            p->res_launches++;
         }
     } else {
         for (int l = 0; l < L; ++l) {
@@ -645,10 +675,20 @@ static void plan_gn_step(Opt_Plan* p)
     if (res && plan_resident_pack(p)) {
         // new deal of solves to workgroups (the frames' active-tile counts changed): upload the tables (pageable
         // source: staged before the call returns; stream ordered behind earlier launches) and re-capture
-        HC(hipMemcpyAsync(p->d_wgmap, p->h_wgmap.data(), p->h_wgmap.size() * sizeof(ResWg), hipMemcpyHostToDevice,
-                          st->stream));
+        if (p->hole_pending) {
+            std::vector<ResWg> holed = p->h_wgmap;
+            for (ResWg& w : holed)
+                if (w.slot >= 0 && w.wgs > 1 && w.rank == w.wgs - 1) { w = ResWg{-1, 0, 0, 0}; break; }
+            HC(hipStreamSynchronize(st->stream));
+            HC(hipMemcpy(p->d_wgmap, holed.data(), holed.size() * sizeof(ResWg), hipMemcpyHostToDevice));
+            p->hole_pending = false;
+        } else {
+            HC(hipMemcpyAsync(p->d_wgmap, p->h_wgmap.data(), p->h_wgmap.size() * sizeof(ResWg), hipMemcpyHostToDevice,
+                              st->stream));
+        }
         plan_drop_graph(p);
     }
+    if (res) p->res_launches += (unsigned)p->res_sets;          // launches executed (graph replays included)
     if (!graph_ok) {
         enqueue_gn_step(p, st->stream);
         return;
@@ -706,7 +746,6 @@ static void plan_init(Opt_Plan* p)
     p->sp.nIter = 0;
     plan_reserve(p, p->sp.lIterations, p->sp.nIterations + 1);
     plan_upload_slots(p);
-    plan_analyse_for_resident(p);
     if (p->lazy_cost && !p->cost_wanted && p->st->verbosity == 0) return;
     HC(hipMemsetAsync(p->pd.costred, 0, (size_t)p->nb * p->pd.ncost * NSHARD * sizeof(double), p->st->stream));
     if (!p->lazy_cost || p->st->verbosity > 0 || p->sp.nIterations == 0) plan_cost(p, 0);
@@ -717,10 +756,15 @@ static int plan_step(Opt_Plan* p)
 {
     if (p->sp.nIter < p->sp.nIterations) {
         plan_upload_slots(p);
+        // the caller may have changed Mask / UrShape since Init or the last Step (Opt.h:58-66)
+        if (!p->res_frames &&
+            (p->sp.nIter == 0 || (p->res_capable && p->st->use_resident && p->st->res_cooldown == 0)))
+            plan_analyse_for_resident(p);
         const bool used_res = plan_resident_eligible(p);
         plan_gn_step(p);
-        if (used_res && !p->res_frames) {
-            // drop-in plan: the caller may read the unknowns right after this Step, so make sure it happened
+        if (used_res && (!p->res_frames || p->st->verbosity > 0)) {
+            // drop-in plan: the caller may read the unknowns right after this Step, so make sure it happened (a verbose
+            // frame solve reads the costs below: same check, instead of at the end of ArapFlow_SolverSolve)
             HC(hipStreamSynchronize(p->st->stream));
             if (plan_resident_failed(p)) plan_gn_step(p);          // X untouched: redo on the two-kernel path
         }
@@ -951,6 +995,7 @@ void ArapFlow_FreeState(Opt_State* st)
 {
     if (!st) return;
     (void)hipStreamDestroy(st->cap);
+    if (st->own_stream) (void)hipStreamDestroy(st->own_stream);
     (void)hipEventDestroy(st->t0);
     (void)hipEventDestroy(st->t1);
     st->ktimer.clear();
@@ -1023,8 +1068,9 @@ void Opt_SetSolverParameter(Opt_State*, Opt_Plan* plan, const char* name, void* 
     if (plan->st->verbosity > 0) printf("Warning: tried to set nonexistent solver parameter %s\n", name);
 }
 
-void Opt_ProblemInit(Opt_State*, Opt_Plan* plan, void** problemparams)
+void Opt_ProblemInit(Opt_State* state, Opt_Plan* plan, void** problemparams)
 {
+    if (state && state->res_cooldown > 0) --state->res_cooldown;
     plan->nb = 1;
     slot_from_params(plan->hslots[0], problemparams);
     if (plan->kind == 1) plan_init_lm(plan); else plan_init(plan);
@@ -1053,7 +1099,11 @@ double Opt_ProblemCurrentCost(Opt_State*, Opt_Plan* plan)
 // ---------------------------------------------------------------------------------------------
 const char* ArapFlow_Version(void) { return ARAPOPT_VERSION; }
 
-void ArapFlow_SetResident(Opt_State* state, int on) { state->use_resident = on != 0; }
+void ArapFlow_SetResident(Opt_State* state, int on)
+{
+    state->use_resident = on != 0;
+    if (on) { state->res_cooldown = 0; state->res_backoff = 8; }     // an explicit "on" also ends a pause after a timeout
+}
 
 int ArapFlow_SetTile(Opt_State* state, int tile_x, int tile_y)
 {
@@ -1088,6 +1138,14 @@ int ArapFlow_KernelTime(Opt_State* state, const char* kernel_name, double* total
 }
 
 void ArapFlow_SetStream(Opt_State* state, void* hip_stream) { state->stream = (hipStream_t)hip_stream; }
+
+int ArapFlow_UseOwnStream(Opt_State* state)
+{
+    if (!state) return -1;
+    if (!state->own_stream) HC(hipStreamCreateWithFlags(&state->own_stream, hipStreamNonBlocking));
+    state->stream = state->own_stream;
+    return 0;
+}
 
 void ArapFlow_TimerBegin(Opt_State* state) { HC(hipEventRecord(state->t0, state->stream)); }
 
@@ -1205,6 +1263,8 @@ __global__ __launch_bounds__(256) void k_frame_ramp(const FrameDev* fr, int W, i
 
 }  // namespace arap
 
+extern "C" int ArapFlow_SolverWait(ArapFlow_Solver* s);
+
 struct ArapFlow_Solver {
     Opt_State* st = nullptr;
     int W = 0, H = 0, N = 0, batch = 0;
@@ -1218,7 +1278,92 @@ struct ArapFlow_Solver {
     uint64_t last_pcg = 0, last_active = 0, last_grid = 0;
     unsigned last_n = 0;
     int last_cost_index = 0;
+    // Host <-> device traffic runs on the solver's own copy stream through pinned staging, ordered against the
+    // state's compute stream by events, so that a host can upload the next batch into one solver object and download
+    // the previous results from it while ANOTHER solver object's solve occupies the compute stream (arap_deform).
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_up = nullptr, ev_done = nullptr, ev_dl = nullptr;
+    char* pin_in = nullptr;          // [batch] x {T float2[N], mask u8[N], rgb u8[3N]}
+    char* pin_out = nullptr;         // [batch] x {flow float2[N], rgb u8[3N], mask u8[N]}   (allocated on first download)
+    size_t pin_in_slot = 0, pin_out_slot = 0;
+    bool uploads_pending = false;    // SetFrame since the last solve: the solve waits for ev_up
+    bool inflight = false;           // a solve has been enqueued and not waited for
+    bool retried = false;            // the last wait redid the schedule on the two-kernel path
+    unsigned a_n = 0, a_numIter = 0, a_nIt = 0, a_lIt = 0;
+    int a_warp = 0, a_download = 0;
 };
+
+static void solver_enqueue_warp(ArapFlow_Solver* s, unsigned nframes)
+{
+    Opt_State* st = s->st;
+    std::vector<WarpJob> jobs(nframes);
+    for (unsigned b = 0; b < nframes; ++b) {
+        const FrameDev& f = s->hfr[b];
+        WarpJob& j = jobs[b];
+        j.field = f.O; j.flow_in = nullptr;
+        j.rgb = s->has_rgb[b] ? f.rgb : nullptr;
+        j.mask = f.mask; j.flow_out = f.flow; j.key = f.key;
+        j.out_rgb = s->has_rgb[b] ? f.out_rgb : nullptr;
+        j.out_mask = f.out_mask;
+    }
+    HC(hipMemcpyAsync(s->djobs, jobs.data(), sizeof(WarpJob) * nframes, hipMemcpyHostToDevice, st->stream));
+    const dim3 g((s->W + 63) / 64, (s->H + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_warp_raster, g, dim3(64, 4), 0, st->stream, s->djobs, s->W, s->H);
+    hipLaunchKernelGGL(k_warp_resolve, dim3((s->N + 255) / 256, 1, nframes), dim3(256), 0, st->stream, s->djobs,
+                       s->N);
+}
+
+// the whole schedule of slots [0, a_n) on the compute stream (+ warp, + download on the copy stream), no waiting
+static void solver_enqueue(ArapFlow_Solver* s)
+{
+    Opt_State* st = s->st;
+    Opt_Plan* p = s->plan;
+    const unsigned nframes = s->a_n, numIter = s->a_numIter;
+    p->nb = (int)nframes;
+    p->sp.nIterations = (int)s->a_nIt;
+    p->sp.lIterations = (int)s->a_lIt;
+    if (s->uploads_pending) {
+        HC(hipEventRecord(s->ev_up, s->copy));
+        HC(hipStreamWaitEvent(st->stream, s->ev_up, 0));
+        s->uploads_pending = false;
+    }
+    const dim3 g1((s->N + 255) / 256, 1, nframes);
+    // preSingleSolve = resetGPU (CombinedSolver.h:191-193)
+    hipLaunchKernelGGL(k_frame_reset, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N);
+    for (unsigned i = 0; i < numIter; ++i) {
+        const float alpha = (float)(i + 1) / (float)numIter;          // CombinedSolver.h:199-201
+        hipLaunchKernelGGL(k_frame_ramp, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N, alpha);
+        p->lazy_cost = true;
+        p->cost_wanted = i + 1 == numIter;
+        plan_init(p);
+        while (plan_step(p) != 0) {}
+    }
+    if (s->a_warp) solver_enqueue_warp(s, nframes);
+    HC(hipEventRecord(s->ev_done, st->stream));
+    if (s->a_download) {
+        if (!s->pin_out) {
+            const size_t N = s->N;
+            s->pin_out_slot = align_up(12 * N, 256);
+            HC(hipHostMalloc((void**)&s->pin_out, s->pin_out_slot * s->batch, hipHostMallocDefault));
+        }
+        HC(hipStreamWaitEvent(s->copy, s->ev_done, 0));
+        const size_t N = s->N;
+        for (unsigned b = 0; b < nframes; ++b) {
+            const FrameDev& f = s->hfr[b];
+            char* o = s->pin_out + s->pin_out_slot * b;
+            HC(hipMemcpyAsync(o, f.flow, 8 * N, hipMemcpyDeviceToHost, s->copy));
+            if (s->has_rgb[b]) HC(hipMemcpyAsync(o + 8 * N, f.out_rgb, 3 * N, hipMemcpyDeviceToHost, s->copy));
+            HC(hipMemcpyAsync(o + 11 * N, f.out_mask, N, hipMemcpyDeviceToHost, s->copy));
+        }
+        HC(hipEventRecord(s->ev_dl, s->copy));
+    }
+    s->last_cost_index = p->sp.nIter;
+    s->last_n = nframes;
+    s->last_pcg = (uint64_t)numIter * s->a_nIt * s->a_lIt;
+    s->last_active = 0;
+    for (unsigned b = 0; b < nframes; ++b) s->last_active += s->nactive[b];
+    s->last_grid = (uint64_t)nframes * s->N;
+}
 
 extern "C" {
 
@@ -1254,6 +1399,12 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
     s->djobs = (WarpJob*)take(align_up(sizeof(WarpJob) * batch, 256));
     HC(hipMemcpyAsync(s->dfr, s->hfr.data(), sizeof(FrameDev) * batch, hipMemcpyHostToDevice, st->stream));
     HC(hipStreamSynchronize(st->stream));
+    HC(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+    HC(hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    HC(hipEventCreateWithFlags(&s->ev_dl, hipEventDisableTiming));
+    s->pin_in_slot = align_up(12 * N, 256);
+    HC(hipHostMalloc((void**)&s->pin_in, s->pin_in_slot * batch, hipHostMallocDefault));
     s->has_rgb.assign(batch, 0);
     s->nactive.assign(batch, 0);
     const float wfit = sqrtf(100.0f), wreg = sqrtf(0.01f);   // CombinedSolver.h:173-177
@@ -1269,7 +1420,13 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
 void ArapFlow_SolverFree(ArapFlow_Solver* s)
 {
     if (!s) return;
+    if (s->inflight) (void)ArapFlow_SolverWait(s);
+    (void)hipStreamSynchronize(s->copy);
     plan_free(s->plan);
+    (void)hipStreamDestroy(s->copy);
+    (void)hipEventDestroy(s->ev_up); (void)hipEventDestroy(s->ev_done); (void)hipEventDestroy(s->ev_dl);
+    if (s->pin_in) (void)hipHostFree(s->pin_in);
+    if (s->pin_out) (void)hipHostFree(s->pin_out);
     (void)hipFree(s->block);
     delete s;
 }
@@ -1278,104 +1435,136 @@ int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rg
                             const int32_t* cons, unsigned ncons, int add_border_pins)
 {
     if (!s || slot >= (unsigned)s->batch || !mask_red || (ncons && !cons)) return -1;
+    // the previous solve of THIS solver may still read the slot's images and tile lists
+    if (s->inflight && ArapFlow_SolverWait(s) != 0) return -1;
     const int W = s->W, H = s->H;
     const size_t N = s->N;
+    // the staging of this slot may still be the source of an earlier upload
+    HC(hipStreamSynchronize(s->copy));
+    char* stage = s->pin_in + s->pin_in_slot * slot;
+    float2* T = (float2*)stage;
+    uint8_t* smask = (uint8_t*)(stage + 8 * N);
+    uint8_t* srgb = (uint8_t*)(stage + 9 * N);
     // host pre-pass of setConstraintImage's placement loop (CombinedSolver.h:230-240): file
     // constraints first, then border pins (main.cpp:130-136); later entries overwrite earlier ones;
     // only where Mask == 0.
-    std::vector<float2> T(N, make_float2(NAN, NAN));
+    const float2 none = make_float2(NAN, NAN);
+    for (size_t i = 0; i < N; ++i) T[i] = none;
     auto place = [&](int x, int y, int tx, int ty) {
         if (x < 0 || x >= W || y < 0 || y >= H) return;
         if (mask_red[x + (size_t)W * y] == 0) T[x + (size_t)W * y] = make_float2((float)tx, (float)ty);
     };
     for (unsigned k = 0; k < ncons; ++k) place(cons[4 * k], cons[4 * k + 1], cons[4 * k + 2], cons[4 * k + 3]);
-    if (add_border_pins)
-        for (int y = 0; y < H; ++y)
-            for (int x = 0; x < W; ++x)
-                if (y == 0 || x == 0 || y == H - 1 || x == W - 1) place(x, y, x, y);
+    if (add_border_pins) {
+        for (int x = 0; x < W; ++x) place(x, 0, x, 0);
+        for (int y = 1; y + 1 < H; ++y) { place(0, y, 0, y); if (W > 1) place(W - 1, y, W - 1, y); }
+        if (H > 1) for (int x = 0; x < W; ++x) place(x, H - 1, x, H - 1);
+    }
+    memcpy(smask, mask_red, N);
+    if (rgb) memcpy(srgb, rgb, 3 * N);
+    // active vertices and active 64x4 tiles of this frame, row-major (resident path work list)
     uint64_t na = 0;
-    for (size_t i = 0; i < N; ++i) na += mask_red[i] == 0;
-    s->nactive[slot] = na;
-    // active 64x4 tiles of this frame, row-major (resident path work list)
     std::vector<int> tiles;
     {
         const int tX = s->plan->pd.tilesX, tY = s->plan->pd.tilesY;
-        for (int ty = 0; ty < tY; ++ty)
-            for (int tx = 0; tx < tX; ++tx) {
-                bool any = false;
-                for (int y = ty * TILE_Y; y < H && y < (ty + 1) * TILE_Y && !any; ++y)
-                    for (int x = tx * TILE_X; x < W && x < (tx + 1) * TILE_X; ++x)
-                        if (mask_red[x + (size_t)W * y] == 0) { any = true; break; }
-                if (any) tiles.push_back(ty * tX + tx);
+        std::vector<uint8_t> colact(tX);
+        for (int ty = 0; ty < tY; ++ty) {
+            std::fill(colact.begin(), colact.end(), 0);
+            for (int y = ty * TILE_Y; y < H && y < (ty + 1) * TILE_Y; ++y) {
+                const uint8_t* row = mask_red + (size_t)W * y;
+                for (int tx = 0; tx < tX; ++tx) {
+                    const int x1 = std::min(W, (tx + 1) * TILE_X);
+                    unsigned cnt = 0;
+                    for (int x = tx * TILE_X; x < x1; ++x) cnt += row[x] == 0;
+                    na += cnt;
+                    colact[tx] |= cnt != 0;
+                }
             }
+            for (int tx = 0; tx < tX; ++tx)
+                if (colact[tx]) tiles.push_back(ty * tX + tx);
+        }
     }
-    HC(hipStreamSynchronize(s->st->stream));
-    plan_upload_tiles(s->plan, (int)slot, tiles);
+    s->nactive[slot] = na;
+    plan_upload_tiles(s->plan, (int)slot, tiles, s->copy);
     const FrameDev& f = s->hfr[slot];
-    HC(hipMemcpy(f.T, T.data(), N * sizeof(float2), hipMemcpyHostToDevice));
-    HC(hipMemcpy(f.mask, mask_red, N, hipMemcpyHostToDevice));
-    if (rgb) HC(hipMemcpy(f.rgb, rgb, 3 * N, hipMemcpyHostToDevice));
+    HC(hipMemcpyAsync(f.T, T, N * sizeof(float2), hipMemcpyHostToDevice, s->copy));
+    HC(hipMemcpyAsync(f.mask, smask, N, hipMemcpyHostToDevice, s->copy));
+    if (rgb) HC(hipMemcpyAsync(f.rgb, srgb, 3 * N, hipMemcpyHostToDevice, s->copy));
     s->has_rgb[slot] = rgb ? 1 : 0;
+    s->uploads_pending = true;
+    return 0;
+}
+
+int ArapFlow_SolverSolveAsync(ArapFlow_Solver* s, unsigned nframes, unsigned numIter, unsigned nIterations,
+                              unsigned lIterations, int warp, int download)
+{
+    if (!s || nframes == 0 || nframes > (unsigned)s->batch || numIter == 0) return -1;
+    if (s->inflight && ArapFlow_SolverWait(s) != 0) return -1;
+    Opt_State* st = s->st;
+    HC(hipSetDevice(st->device));
+    const bool paused = st->res_cooldown > 0;                 // this call runs on the two-kernel path: counts as one
+    s->a_n = nframes; s->a_numIter = numIter; s->a_nIt = nIterations; s->a_lIt = lIterations;
+    s->a_warp = warp; s->a_download = download;
+    s->retried = false;
+    solver_enqueue(s);
+    if (paused) --st->res_cooldown;
+    s->inflight = true;
+    return 0;
+}
+
+int ArapFlow_SolverWait(ArapFlow_Solver* s)
+{
+    if (!s) return -1;
+    if (!s->inflight) return 0;
+    Opt_State* st = s->st;
+    Opt_Plan* p = s->plan;
+    HC(hipEventSynchronize(s->ev_done));
+    // The resident path needs all its workgroups co-resident; if a launch gave up (GPU shared with another process) the
+    // device skipped every later update: redo the whole schedule once, now on the two-kernel path (plan_resident_failed
+    // pauses the resident path), from the reset.
+    if (p->res_launches > 0 && plan_resident_failed(p)) {
+        HC(hipStreamSynchronize(s->copy));
+        solver_enqueue(s);
+        s->retried = true;
+        HC(hipEventSynchronize(s->ev_done));
+        if (plan_resident_failed(p)) {
+            fprintf(stderr, "arapopt: the two-kernel retry reported a resident failure\n");
+            s->inflight = false;
+            return -2;
+        }
+    } else if (p->res_launches > 0) {
+        st->res_backoff = 8;
+    }
+    if (s->a_download) HC(hipEventSynchronize(s->ev_dl));
+    s->inflight = false;
     return 0;
 }
 
 int ArapFlow_SolverSolve(ArapFlow_Solver* s, unsigned nframes, unsigned numIter, unsigned nIterations,
                          unsigned lIterations)
 {
-    if (!s || nframes == 0 || nframes > (unsigned)s->batch || numIter == 0) return -1;
-    Opt_State* st = s->st;
-    Opt_Plan* p = s->plan;
-    HC(hipSetDevice(st->device));
-    p->nb = (int)nframes;
-    p->sp.nIterations = (int)nIterations;
-    p->sp.lIterations = (int)lIterations;
-    const dim3 g1((s->N + 255) / 256, 1, nframes);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool used_res = plan_resident_eligible(p);
-        // preSingleSolve = resetGPU (CombinedSolver.h:191-193)
-        hipLaunchKernelGGL(k_frame_reset, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N);
-        for (unsigned i = 0; i < numIter; ++i) {
-            const float alpha = (float)(i + 1) / (float)numIter;          // CombinedSolver.h:199-201
-            hipLaunchKernelGGL(k_frame_ramp, g1, dim3(256), 0, st->stream, s->dfr, s->W, s->N, alpha);
-            p->lazy_cost = true;
-            p->cost_wanted = i + 1 == numIter;
-            plan_init(p);
-            while (plan_step(p) != 0) {}
-        }
-        if (!used_res) break;
-        // the resident path needs all its workgroups co-resident; if a launch gave up (GPU shared with another
-        // process), redo the whole schedule on the two-kernel path: one synchronisation per solve call
-        HC(hipStreamSynchronize(st->stream));
-        if (!plan_resident_failed(p)) break;
-    }
-    s->last_cost_index = p->sp.nIter;
-    s->last_n = nframes;
-    s->last_pcg = (uint64_t)numIter * nIterations * lIterations;
-    s->last_active = 0;
-    for (unsigned b = 0; b < nframes; ++b) s->last_active += s->nactive[b];
-    s->last_grid = (uint64_t)nframes * s->N;
-    return 0;
+    const int rc = ArapFlow_SolverSolveAsync(s, nframes, numIter, nIterations, lIterations, 0, 0);
+    return rc != 0 ? rc : ArapFlow_SolverWait(s);
 }
 
 int ArapFlow_SolverWarp(ArapFlow_Solver* s, unsigned nframes)
 {
     if (!s || nframes == 0 || nframes > (unsigned)s->batch) return -1;
-    Opt_State* st = s->st;
-    std::vector<WarpJob> jobs(nframes);
-    for (unsigned b = 0; b < nframes; ++b) {
-        const FrameDev& f = s->hfr[b];
-        WarpJob& j = jobs[b];
-        j.field = f.O; j.flow_in = nullptr;
-        j.rgb = s->has_rgb[b] ? f.rgb : nullptr;
-        j.mask = f.mask; j.flow_out = f.flow; j.key = f.key;
-        j.out_rgb = s->has_rgb[b] ? f.out_rgb : nullptr;
-        j.out_mask = f.out_mask;
-    }
-    HC(hipMemcpyAsync(s->djobs, jobs.data(), sizeof(WarpJob) * nframes, hipMemcpyHostToDevice, st->stream));
-    const dim3 g((s->W + 63) / 64, (s->H + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_warp_raster, g, dim3(64, 4), 0, st->stream, s->djobs, s->W, s->H);
-    hipLaunchKernelGGL(k_warp_resolve, dim3((s->N + 255) / 256, 1, nframes), dim3(256), 0, st->stream, s->djobs,
-                       s->N);
+    if (s->inflight && ArapFlow_SolverWait(s) != 0) return -1;
+    solver_enqueue_warp(s, nframes);
+    return 0;
+}
+
+int ArapFlow_SolverHostResults(ArapFlow_Solver* s, unsigned slot, const float** flow, const uint8_t** warped_rgb,
+                               const uint8_t** warped_mask)
+{
+    if (!s || slot >= (unsigned)s->batch || !s->pin_out || !s->a_download || slot >= s->a_n) return -1;
+    if (s->inflight && ArapFlow_SolverWait(s) != 0) return -1;
+    const size_t N = s->N;
+    const char* o = s->pin_out + s->pin_out_slot * slot;
+    if (flow) *flow = (const float*)o;
+    if (warped_rgb) *warped_rgb = s->has_rgb[slot] ? (const uint8_t*)(o + 8 * N) : nullptr;
+    if (warped_mask) *warped_mask = (const uint8_t*)(o + 11 * N);
     return 0;
 }
 
@@ -1383,15 +1572,18 @@ int ArapFlow_SolverGetResults(ArapFlow_Solver* s, unsigned slot, float* flow, ui
                               uint8_t* warped_mask, float* offset, float* angle, double* final_cost)
 {
     if (!s || slot >= (unsigned)s->batch) return -1;
+    if (s->inflight && ArapFlow_SolverWait(s) != 0) return -1;
     HC(hipStreamSynchronize(s->st->stream));
     plan_check_resident_error(s->plan);
     const FrameDev& f = s->hfr[slot];
     const size_t N = s->N;
-    if (flow) HC(hipMemcpy(flow, f.flow, N * sizeof(float2), hipMemcpyDeviceToHost));
-    if (warped_rgb) HC(hipMemcpy(warped_rgb, f.out_rgb, 3 * N, hipMemcpyDeviceToHost));
-    if (warped_mask) HC(hipMemcpy(warped_mask, f.out_mask, N, hipMemcpyDeviceToHost));
-    if (offset) HC(hipMemcpy(offset, f.O, N * sizeof(float2), hipMemcpyDeviceToHost));
-    if (angle) HC(hipMemcpy(angle, f.A, N * sizeof(float), hipMemcpyDeviceToHost));
+    hipStream_t cs = s->copy;
+    if (flow) HC(hipMemcpyAsync(flow, f.flow, N * sizeof(float2), hipMemcpyDeviceToHost, cs));
+    if (warped_rgb) HC(hipMemcpyAsync(warped_rgb, f.out_rgb, 3 * N, hipMemcpyDeviceToHost, cs));
+    if (warped_mask) HC(hipMemcpyAsync(warped_mask, f.out_mask, N, hipMemcpyDeviceToHost, cs));
+    if (offset) HC(hipMemcpyAsync(offset, f.O, N * sizeof(float2), hipMemcpyDeviceToHost, cs));
+    if (angle) HC(hipMemcpyAsync(angle, f.A, N * sizeof(float), hipMemcpyDeviceToHost, cs));
+    HC(hipStreamSynchronize(cs));
     if (final_cost) *final_cost = plan_read_cost(s->plan, (int)slot, s->last_cost_index);
     return 0;
 }

@@ -11,9 +11,18 @@ the timed region.  Workload = BASELINE.json configs[1]: single-segment DAVIS-sha
 Frames shard across ranks with no collective: weak scaling, value = all frames / max time.
 
 One JSON line on rank 0: metric/value/... plus
-  roofline     : dominant PCG kernel; achieved = algorithmic bytes per launch / average launch
-                 duration measured with HIP events around every launch (a separate, un-graphed pass)
+  roofline     : dominant PCG kernel.  achieved / peak / frac = SURVEY 8(d)'s figure: algorithmic bytes per launch /
+                 average launch duration measured with HIP events around every launch (a separate, un-graphed pass)
+                 against the 8 TB/s HBM peak.  The resident kernel keeps the PCG state on chip, so that figure exceeds 1
+                 and does NOT bind; `bound` names the ceiling that does, and the line carries the real utilisations:
+                 hbm_frac_by_counters (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch / launch time / peak),
+                 valu_issue_frac (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x launch cycles)), wait_frac (share
+                 of an iteration inside the two group waits, instrumented build).  Those three come from
+                 profiles/*_counters.json (tools/collect_profile.py) and are quoted only when that record was made for
+                 this workload AND for the kernel sources as they are now (else null + the reason).
   cpu_baseline : the CPU oracle (kind "port") timed on this host on a bounded sample
+  parity_check : frame 0 (its first segment with --multseg) of the timed steps, Offset and Angle, against the oracle's
+                 result from the cpu_baseline leg (same schedule): bit_equal true / false (outside the timed region)
 """
 import argparse
 import json
@@ -22,6 +31,8 @@ import sys
 import time
 
 import numpy as np
+
+import hashlib
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -48,49 +59,77 @@ def parse():
     ap.add_argument("--fd", type=int, default=1, help="frame distance of the synthetic matches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--stamps", action="store_true",
+                    help="diagnostic (needs ARAPOPT_STAMPS=1): print the per-phase times of the resident kernel's last launch")
     return ap.parse_args()
 
 
-def _time_oracle(frame, threads, numIter, nIter, lIter):
-    """wall time of the CPU oracle in a FRESH process (OMP_NUM_THREADS must be set before the OpenMP runtime starts;
-    this process already runs torch's)"""
+def _field_hash(offset, angle):
+    return hashlib.sha256(np.ascontiguousarray(offset, np.float32).tobytes() +
+                          np.ascontiguousarray(angle, np.float32).tobytes()).hexdigest()
+
+
+def _time_oracle(spec, threads, numIter, nIter, lIter, first_only=False):
+    """wall time of the CPU oracle on the solves of ONE frame of the workload, in a FRESH process (OMP_NUM_THREADS
+    must be set before the OpenMP runtime starts; this process already runs torch's).  Returns (seconds, sha256 of the
+    first solve's Offset + Angle)."""
     import subprocess
-    H, W = frame["mask_red"].shape
-    code = ("import sys,time,json,numpy as np;sys.path.insert(0,%r);from oracle import oracle as orc;"
-            "from arap_flow_amd import synth;f=synth.make_frame(%d,%d,seed=%d,full_mask=%r);t=time.time();"
-            "orc.frame(f['mask_red'],f['constraints'],numIter=%d,nIterations=%d,lIterations=%d,dtype=np.float32,mode=1,trig=1);"
-            "print(json.dumps(time.time()-t))" % (ROOT, W, H, frame.get("seed", 0), bool((frame["mask_red"] == 0).all()),
-                                                  numIter, nIter, lIter))
+    code = ("import sys,time,json,hashlib,numpy as np;sys.path.insert(0,%r);from oracle import oracle as orc;"
+            "from arap_flow_amd import synth;f=synth.make_frame(%d,%d,seed=%d,K=%d,fd=%d,full_mask=%r);"
+            "sv=synth.segment_masks(f) if %r else [f];sv=sv[:1] if %r else sv;t=time.time();h=None\n"
+            "for g in sv:\n"
+            "    O,A,c=orc.frame(g['mask_red'],g['constraints'],numIter=%d,nIterations=%d,lIterations=%d,dtype=np.float32,mode=1,trig=1)\n"
+            "    h=h or hashlib.sha256(np.ascontiguousarray(O,np.float32).tobytes()+np.ascontiguousarray(A,np.float32).tobytes()).hexdigest()\n"
+            "print(json.dumps([time.time()-t,h,len(sv)]))"
+            % (ROOT, spec["W"], spec["H"], spec["seed"], spec["K"], spec["fd"], spec["full"], spec["multseg"], first_only,
+               numIter, nIter, lIter))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_WAIT_POLICY="active"),
-                       capture_output=True, text=True, timeout=900)
-    return float(r.stdout.strip().splitlines()[-1])
+                       capture_output=True, text=True, timeout=1500)
+    dt, h, n = json.loads(r.stdout.strip().splitlines()[-1])
+    return float(dt), h, int(n)
 
 
-def cpu_baseline(frame, schedule):
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(spec, schedule):
     """The CPU oracle (same algorithm, float32, OpenMP over rows; kind "port") on a bounded sample of the same
-    workload, on this box's CPU share (a 1-GPU box grants 16 of the host's cores).  Only this leg of the bench
-    touches oracle/."""
+    workload -- one frame, all its segment solves -- on this box's CPU share (a 1-GPU box grants 16 of the host's
+    cores).  Only this leg of the bench touches oracle/.  Also returns the hash of the first solve's result for the
+    parity check."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = min(cores, int(os.environ.get("ARAP_CPU_BASELINE_THREADS", "16")))
     numIter, nIter, lIter = schedule
-    ns = min(numIter, 19)
-    dt = _time_oracle(frame, cores, ns, nIter, lIter)
+    # bound the sample to ~30 s: the full schedule of a 854x480 DAVIS-shaped frame is ~15 s on 16 cores; larger or
+    # fuller frames get fewer ramp steps (the cost per ramp step is constant), scaled
+    work = spec["active"] / 102480.0 * (numIter * nIter * lIter) / 60800.0
+    ns = numIter if work <= 2.2 else max(1, int(numIter * 2.2 / work))
+    dt, h, nsolves = _time_oracle(spec, cores, ns, nIter, lIter)
     fps = 1.0 / (dt * numIter / ns)
-    out = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": "%d of %d ramp steps (x %d GN x %d PCG iterations) of one frame of the same workload, %.1f s"
-                     % (ns, numIter, nIter, lIter, dt),
-           "pcg_iters_per_s": ns * nIter * lIter / dt}
+    out = {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+           "sample": "%d of %d ramp steps (x %d GN x %d PCG iterations) of one frame (%d solve%s) of the same workload, %.1f s"
+                     % (ns, numIter, nIter, lIter, nsolves, "" if nsolves == 1 else "s", dt),
+           "pcg_iters_per_s": ns * nIter * lIter * nsolves / dt}
     try:                                                      # the same code on ONE thread (SURVEY 8d asks for both)
         n1 = min(nIter, 8)
-        t1 = _time_oracle(frame, 1, 1, n1, lIter)
-        out["single_thread"] = {"value": 1.0 / (t1 * numIter * nIter / n1), "unit": "frames/s", "cores": 1,
-                                "sample": "1 ramp step x %d GN x %d PCG iterations, %.1f s, scaled" % (n1, lIter, t1)}
+        scale = max(1.0, spec["active"] / 102480.0)
+        n1 = max(1, int(n1 / scale))
+        t1, _, _ = _time_oracle(spec, 1, 1, n1, lIter, first_only=True)
+        out["single_thread"] = {"value": 1.0 / (t1 * nsolves * numIter * nIter / n1), "unit": "frames/s", "cores": 1,
+                                "sample": "1 ramp step x %d GN x %d PCG iterations of one solve, %.1f s, scaled" % (n1, lIter, t1)}
     except Exception as e:                                    # never fail the bench over the extra figure
         out["single_thread"] = {"error": str(e)[:200]}
-    return out
+    return out, (h if ns == numIter else None)
 
 
 def main():
@@ -113,6 +152,7 @@ def main():
         else:
             dist.init_process_group(backend)
     from arap_flow_amd import opt, shard, synth
+    from tools import profile_key
 
     W, H = a.size
     numIter, nIter, lIter = a.schedule
@@ -165,16 +205,34 @@ def main():
     for _ in range(a.steps):
         step()
     ev_ms = st.timer_end()
+    t_local = time.perf_counter() - t0              # this rank's own time for the K steps (its frames only)
     barrier()
     dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dist, device="cuda" if backend == "nccl" else "cpu")
+    dev = "cuda" if backend == "nccl" else "cpu"
+    dt = shard.max_over_ranks(dt, dist, device=dev)
+    per_rank_ms = [1e3 * t_local / a.steps]
+    seen_world = 1
+    if dist is not None:
+        t = torch.tensor([1e3 * t_local / a.steps], dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        per_rank_ms = [float(g.item()) for g in got]
+        seen_world = dist.get_world_size()
     stats = fs.stats()
     total_frames = world * B * a.steps
     fps = total_frames / dt
     pcg_per_frame = stats["pcg_iterations_per_frame"]
     n_active = stats["active_vertices"] / B          # per frame (all its segments)
     n_grid = W * H
+    # result of the timed steps, frame 0 (its first segment), for the parity check below: taken NOW, before the
+    # kernel-timing pass re-solves with another schedule
+    parity_hash = None
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        r_timed = fs.results(0, want_rgb=False)
+        parity_hash = _field_hash(r_timed["offset"], r_timed["angle"])
+        del r_timed
 
+    sig = profile_key.signature(a.workload, W, H, S, K if a.multseg else 1, a.fd, B)
     out = {
         "metric": "ARAP solve+warp frames/sec at 854x480 mesh",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -192,10 +250,15 @@ def main():
                    "active_vertices_per_frame": n_active, "grid_vertices_per_frame": n_grid},
         "pcg_iters_per_s": fps * pcg_per_frame,
         "hip_event_ms_per_step_rank0": ev_ms / a.steps,
+        # multi-GPU bookkeeping: every rank's own time per step (its frames only, before the closing barrier) and the
+        # world size torch.distributed (RCCL) reported -- the scaling curve is computed by the driver from `value`
+        "per_rank_ms_per_step": per_rank_ms, "world_size_seen": seen_world, "backend": backend if world > 1 else None,
+        "profile_signature": sig,
     }
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events around every launch (un-graphed pass) ----------
+        r0 = None
         if not a.no_kernel_timing:
             tl = min(lIter, 400)
             st.set_kernel_timing(True)
@@ -204,6 +267,7 @@ def main():
             kt = {k: st.kernel_time(k) for k in ("PCGResident", "PCGStepA", "PCGStepB")}
             st.set_kernel_timing(False)
             n_act_total = stats["active_vertices"]     # all B frames
+            prof = profile_key.find_counters(sig)
             if kt["PCGResident"] is not None:
                 tot_ms, n = kt["PCGResident"]
                 # one launch = all `tl` PCG iterations of one GN step for the frames in flight;
@@ -211,15 +275,18 @@ def main():
                 bytes_total = 160.0 * n_act_total * tl * 4
                 ach = bytes_total / (tot_ms * 1e-3) / 1e9
                 frames_per_launch = S * 4.0 / n
-                out["roofline"] = {
-                    "bound": "hbm", "kernel": "k_pcg_resident", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": tot_ms / n * 1e3, "launches": n,
+                rl = {
+                    "bound": "valu_issue+group_wait", "kernel": "k_pcg_resident", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "equivalent_GBs": ach,
+                    "avg_launch_us": tot_ms / n * 1e3, "launches": n,
                     "pcg_iterations_per_launch": tl, "frames_per_launch": frames_per_launch,
                     "us_per_pcg_iteration": tot_ms / n * 1e3 / tl,
                     "achieved_vs_grid_vertices": ach * n_grid / n_active, "frac_vs_grid_vertices": ach * n_grid / n_active / HBM_PEAK_GBS,
-                    "note": "algorithmic bytes = 160 B x active vertices x PCG iterations of the launch; the kernel keeps "
-                            "the PCG state in registers/LDS, so its HBM traffic is far below the algorithmic bytes and "
-                            "the fraction may exceed 1 (BASELINE.md section 3)"}
+                    "note": "achieved/frac = SURVEY 8(d): 160 B x active vertices x PCG iterations of the launch / launch "
+                            "time, against the HBM peak.  The kernel keeps the PCG state in registers/LDS, so that "
+                            "ceiling does not bind (frac > 1); what binds is VALU issue during the phases and the latency "
+                            "of the two group-wide sums per iteration: hbm_frac_by_counters, valu_issue_frac, wait_frac"}
+                kname = "k_pcg_resident"
             else:
                 per = {}
                 for k, bytes_v in (("PCGStepA", BYTES_A), ("PCGStepB", BYTES_B)):
@@ -228,20 +295,40 @@ def main():
                     per[k] = {"avg_us": avg_s * 1e6, "launches": n, "GBs_active": bytes_v * n_act_total / avg_s / 1e9,
                               "GBs_grid": bytes_v * n_grid * B / avg_s / 1e9}
                 dom = max(per, key=lambda k: per[k]["avg_us"])
-                out["roofline"] = {"bound": "hbm", "kernel": {"PCGStepA": "k_pcg_a", "PCGStepB": "k_pcg_b"}[dom],
-                                   "achieved": per[dom]["GBs_active"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": per[dom]["GBs_active"] / HBM_PEAK_GBS, "traffic": None,
-                                   "avg_launch_us": per[dom]["avg_us"], "achieved_vs_grid_vertices": per[dom]["GBs_grid"],
-                                   "frac_vs_grid_vertices": per[dom]["GBs_grid"] / HBM_PEAK_GBS, "per_kernel": per,
-                                   "note": "algorithmic bytes = %d (A) / %d (B) per active vertex per launch" % (BYTES_A, BYTES_B)}
-            # HBM bytes per launch from rocprofv3 PMC passes (collected separately, profiles/)
-            tf = os.path.join(ROOT, "profiles", "traffic_%s_b%d.json" % (a.workload, B))
-            if os.path.exists(tf):
-                det = json.load(open(tf)).get(out["roofline"]["kernel"])
-                if det:
-                    out["roofline"]["traffic"] = det.get("hbm_bytes_per_launch")     # bytes per launch
-                    out["roofline"]["traffic_unit"] = "bytes per launch"
-                    out["roofline"]["traffic_detail"] = det
+                kname = {"PCGStepA": "k_pcg_a", "PCGStepB": "k_pcg_b"}[dom]
+                rl = {"bound": "hbm", "kernel": kname,
+                      "achieved": per[dom]["GBs_active"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": per[dom]["GBs_active"] / HBM_PEAK_GBS, "traffic": None,
+                      "avg_launch_us": per[dom]["avg_us"], "achieved_vs_grid_vertices": per[dom]["GBs_grid"],
+                      "frac_vs_grid_vertices": per[dom]["GBs_grid"] / HBM_PEAK_GBS, "per_kernel": per,
+                      "note": "algorithmic bytes = %d (A) / %d (B) per active vertex per launch" % (BYTES_A, BYTES_B)}
+            # counters of the same workload from rocprofv3 passes (collected separately: tools/collect_profile.py)
+            rl["hbm_frac_by_counters"] = rl["valu_issue_frac"] = rl["wait_frac"] = None
+            if prof is None:
+                rl["counters_source"] = None
+                rl["counters_note"] = ("no profiles/*_counters.json matches this workload and the current kernel sources "
+                                       "(hash %s): traffic and utilisation figures withheld" % profile_key.source_hash())
+            else:
+                pf, rec = prof
+                rl["counters_source"] = pf
+                pm = rec.get("pmc", {}).get(kname, {})
+                hb = pm.get("hbm_bytes_per_launch")
+                pmc_ns = rec.get("kernel_stats", {}).get(kname, {}).get("avg_ns")
+                launch_s = rl["avg_launch_us"] * 1e-6
+                if hb:
+                    rl["traffic"] = hb["total"]
+                    rl["traffic_unit"] = "bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes)"
+                    rl["traffic_detail"] = hb
+                    rl["hbm_frac_by_counters"] = hb["total"] / launch_s / 1e9 / HBM_PEAK_GBS
+                if "SQ_ACTIVE_INST_VALU" in pm:
+                    # SQ counters tick in quad-cycles; 256 CUs x 4 SIMDs; nominal 2.4 GHz
+                    rl["valu_issue_frac"] = pm["SQ_ACTIVE_INST_VALU"]["avg_per_launch"] * 4.0 / (1024.0 * launch_s * 2.4e9)
+                if rec.get("stamps"):
+                    rl["wait_frac"] = rec["stamps"].get("wait_frac")
+                    rl["stamps_us_per_iteration"] = rec["stamps"].get("us")
+                if pmc_ns:
+                    rl["rocprof_avg_launch_us"] = pmc_ns * 1e-3
+            out["roofline"] = rl
             out["resident_path"] = stats.get("resident_launches", 0) > 0
             # measured device copy bandwidth next to the nominal peak: 1 GiB float32 copy, read + write
             try:
@@ -258,7 +345,6 @@ def main():
             except Exception as e:
                 out["roofline"]["measured_copy_GBs"] = None
             # warp stage alone: fused flow emission + rasteriser on the GPU (its CPU counterpart: cpu_baseline leg)
-            r0 = None
             try:
                 torch.cuda.synchronize()
                 st.timer_begin()
@@ -268,8 +354,29 @@ def main():
                 r0 = fs.results(0)
             except Exception as e:
                 out["warp_stage"] = {"error": str(e)[:200]}
+        if a.stamps:
+            arr = np.zeros((512, 8), np.uint64)
+            if st.lib.ArapFlow_SolverStamps(fs.h, arr.ctypes.data) == 0:
+                o = arr.astype(np.float64)
+                used = o[:, 0] > 0
+                us = o[used, :5].mean(0) * 0.01 / lIter           # 100 MHz ticks -> us per iteration, mean over workgroups
+                print(json.dumps({"stamps": {"us": dict(zip(["phaseA", "wait1", "phaseB", "wait2", "update"], [float(v) for v in us])),
+                                             "wait_frac": float((us[1] + us[3]) / us.sum()), "workgroups": int(used.sum()),
+                                             "note": "instrumented build (ARAPOPT_STAMPS=1), last resident launch; a workgroup that "
+                                                     "finishes a phase before its CU-mate counts the mate's remaining phase time as wait"}}))
         if not a.no_cpu_baseline and world == 1:               # the CPU side is timed at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(frames[0], a.schedule)
+            f0 = frames[0]
+            spec = dict(W=W, H=H, seed=f0["seed"], K=K, fd=a.fd, full=(a.workload == "full"), multseg=bool(a.multseg),
+                        active=float(n_active))
+            out["cpu_baseline"], oracle_hash = cpu_baseline(spec, a.schedule)
+            # the timed work is the verified work: frame 0 of the timed steps equals the oracle's result bit for bit
+            if oracle_hash is None:
+                out["parity_check"] = {"frame": 0, "bit_equal": None,
+                                       "note": "the CPU sample was cut short of the full schedule (bounded CPU time): no comparison"}
+            else:
+                out["parity_check"] = {"frame": 0, "bit_equal": bool(oracle_hash == parity_hash),
+                                       "what": "sha256 of Offset + Angle of frame 0%s after the timed steps vs the float32 CPU "
+                                               "oracle on the same input and schedule" % (" (first segment)" if a.multseg else "")}
             if not a.no_kernel_timing and r0 is not None:
                 try:                                            # the CPU rasteriser (oracle) on one frame of the same field
                     from oracle import oracle as orc

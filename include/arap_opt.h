@@ -104,6 +104,9 @@ void ArapFlow_FreeState(Opt_State* state);
 /* All work of `state` is enqueued on this HIP stream (hipStream_t as void*; NULL = the null
  * stream, which is what the reference uses: util.t:828). */
 void ArapFlow_SetStream(Opt_State* state, void* hip_stream);
+/* The same with a non-blocking stream the library creates and owns: what a host program that overlaps uploads and
+ * downloads with solves wants (the null stream synchronises with every blocking stream of the process). */
+int ArapFlow_UseOwnStream(Opt_State* state);
 
 /* hipEvent stopwatch on the state's stream, for callers that have no HIP binding of their own
  * (bench.py).  Begin records an event; End records a second one, synchronises on it and returns
@@ -150,17 +153,34 @@ void ArapFlow_SolverFree(ArapFlow_Solver* s);
  *   mask_red  uint8[H][W]    red channel of the mask PNG: 0 = deformable object (CombinedSolver.h:213)
  *   cons      int32[ncons][4] = x1 y1 x2 y2 rows of the constraint file (main.cpp:26-50), file order
  *   add_border_pins  non-zero: append (x,y,x,y) for every border pixel (main.cpp:130-136)
- * Copies to the device on the state's stream (asynchronously; the host buffers are staged
- * internally and may be reused on return).  Returns 0, or -1 on bad arguments. */
+ * The host buffers are staged into pinned memory before the call returns (they may be reused at once); the copies
+ * to the device run on the solver's own copy stream and the next solve waits for them.  If a solve of this solver is
+ * still in flight the call waits for it first.  Returns 0, or -1 on bad arguments. */
 int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rgb, const uint8_t* mask_red,
                             const int32_t* cons, unsigned ncons, int add_border_pins);
 
 /* solveAll (CombinedSolverBase.h:23-31,99-120) for slots [0, nframes): reset (CombinedSolver.h:207-221),
  * then for i < numIter: constraints ramped to alpha = (i+1)/numIter (:199-201,223-242) and one
  * Opt_ProblemSolve with nIterations/lIterations, unknowns carried over.  The application's values
- * are 19, 8, 400 (main.cpp:215-221).  Asynchronous on the state's stream. */
+ * are 19, 8, 400 (main.cpp:215-221).  Returns when the solve has finished. */
 int ArapFlow_SolverSolve(ArapFlow_Solver* s, unsigned nframes, unsigned numIter, unsigned nIterations,
                          unsigned lIterations);
+
+/* Pipelined form of the three calls around a solve, for hosts that keep the GPU busy (arap_deform --serve): enqueue
+ * the whole schedule of slots [0, nframes) on the state's stream -- behind this solver's pending SetFrame uploads,
+ * which travel on the solver's own copy stream from pinned staging -- then, if `warp`, the flow emission + rasteriser,
+ * then, if `download`, the copy of every slot's flow / warped RGB / warped mask into pinned host buffers owned by the
+ * solver (again on the copy stream), and return WITHOUT waiting.  With two solver objects a host uploads batch k+1
+ * and reads back batch k-1 while batch k is being solved.  ArapFlow_SolverWait blocks until everything enqueued for
+ * this solver is done (and, if a resident launch gave up, redoes the schedule on the two-kernel path first); every
+ * other call on a solver with work in flight waits by itself.  ArapFlow_SolverSolve = SolveAsync(.., 0, 0) + Wait.
+ * ArapFlow_SolverHostResults returns pointers into the pinned buffers of a `download` solve (valid until the next
+ * solve of this solver; warped_rgb NULL if the slot has no RGB).  Return 0, -1 on bad arguments. */
+int ArapFlow_SolverSolveAsync(ArapFlow_Solver* s, unsigned nframes, unsigned numIter, unsigned nIterations,
+                              unsigned lIterations, int warp, int download);
+int ArapFlow_SolverWait(ArapFlow_Solver* s);
+int ArapFlow_SolverHostResults(ArapFlow_Solver* s, unsigned slot, const float** flow, const uint8_t** warped_rgb,
+                               const uint8_t** warped_mask);
 
 /* copyResultToCPU + warpField (CombinedSolver.h:280-366) on the device for slots [0, nframes):
  * flow = Offset - grid, and the forward triangle rasterisation of rgb and mask with the solved
@@ -202,14 +222,16 @@ int ArapFlow_SolverLaunchesFor(ArapFlow_Solver* s, unsigned nframes);
  * `table_launches` launches the 512 workgroup entries {solve or -1, rank in its group, group size, granule offset}
  * (int[table_launches][512][4]).  -1 on bad arguments. */
 int ArapFlow_ResidentDeal(const int* active_tiles, unsigned nsolves, int* table, unsigned table_launches);
-/* The drop-in path (Opt_ProblemInit/Step/Solve) takes the resident kernel too when, at Init, the caller's
- * UrShape is the pixel grid on every active vertex (what the application passes, CombinedSolver.h:207-221) and
- * the active tiles fit; the Mask/UrShape buffers analysed at Init must then stay the ones passed to the Steps
- * (other buffers -> general two-kernel path).  Counts resident launches enqueued/captured for this plan. */
+/* The drop-in path (Opt_ProblemInit/Step/Solve) takes the resident kernel too when the caller's UrShape is the
+ * pixel grid on every active vertex (what the application passes, CombinedSolver.h:207-221) and the active tiles
+ * fit.  Mask and UrShape are looked at before EVERY step (the reference re-reads its parameters at every step and
+ * lets the caller change them in between, Opt.h:58-66): new contents or swapped buffers are honoured.  Counts the
+ * resident launches executed for this plan. */
 uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan);
 /* The resident kernel needs its 512 workgroups co-resident.  If a launch gives up at a bounded group wait (e.g.
  * another process is using the GPU), the step's update is skipped on the device, the work is redone on the
- * two-kernel path (same results) and the resident path stays off for this state; this returns 1 from then on. */
+ * two-kernel path (same results) and the resident path pauses for the next 8 solve calls (doubling with every
+ * further timeout, up to 1024; a checked success resets it).  Returns 1 once any launch of this state has given up. */
 int ArapFlow_ResidentFailed(Opt_State* state);
 /* Diagnostic only (env ARAPOPT_STAMPS=1 selects an instrumented build of the resident kernel): copies
  * out[512][8] = per workgroup {phase A, wait 1, phase B, wait 2, update} summed 100 MHz ticks of the

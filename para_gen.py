@@ -2,17 +2,24 @@
 """para_gen -- Python 3 twin of the reference's dataset generator CLI (para_gen.py:341-653), same flags.
 
   python para_gen.py --input IN --output OUT --gpu 0 1 .. 7 [--fd k] [--size W H] [--multseg] [--resume]
-                     [--arap_bin BIN] [--dm_bin BIN | --matches DIR]
+                     [--arap_bin BIN] [--dm_bin BIN | --matches DIR] [--narap N] [--jobs J]
 
 Pipeline per frame pair (para_gen.py:384-567): scan IN/orgRGB/**/N.jpg + IN/orgMasks/**/N.png, pair frame n with
 n+fd, resize/crop, match, filter matches into constraints, composite a random background, write the inverted
-mask (one, or one per segment with --multseg), hand batches of list-file lines to whichever GPU is free (one
-child process per GPU, HIP_VISIBLE_DEVICES per child, no collective), flatten segments, composite the
-background into the warped frame, write OUT/all_files.list.
+mask (one, or one per segment with --multseg), hand list-file lines to whichever GPU has room (one worker process
+per GPU, HIP_VISIBLE_DEVICES per worker, no collective), flatten segments, composite the background into the
+warped frame, write OUT/all_files.list.
 
-Differences from the reference, all at its edges:
-  * --arap_bin defaults to this repo's C++ driver arap_flow_amd/bin/arap_deform (arap_deform.py if it is not built);
-    any executable with the same argv works.  --narap defaults to 64 (reference: 7): see its comment.
+What differs from the reference, and why (a GPU solves ~20 of these frames per second; the reference's loop prepares
+pairs serially and forks one ARAP child per hand-out, which would leave the GPU idle > 90 % of the time):
+  * The front end (resize, match filter, masks, PNG writes) and the back end (flatten, background) run in --jobs worker
+    processes; the parent only schedules.  Output files are the same.
+  * One persistent ARAP worker per GPU id (`arap_deform --serve`, started before the first pair is prepared) is fed
+    list-file lines over a pipe and reports every finished solve; it batches what has accumulated whenever its GPU
+    would otherwise idle.  --narap is the most lines a GPU holds at a time (the reference's dead flag, para_gen.py:628,
+    put to work): lines go to whichever GPU has room, as the reference's GPU queue does (para_gen.py:441-445,560-567).
+    A foreign --arap_bin (argv contract of arap_deform only) is run once per hand-out of up to --narap lines instead.
+  * A worker that exits non-zero fails the run at once (the reference hangs: its GPU id never returns to the queue).
   * DeepMatching (para_gen.py:227-240) is an external binary that is not part of the reference tree.  Either
     pass --dm_bin (called exactly as the reference does) or --matches DIR holding precomputed
     `x1 y1 x2 y2 ...` lines at DIR/<seq>/<frame>.txt.
@@ -20,15 +27,18 @@ Differences from the reference, all at its edges:
     background.
 """
 import argparse
+import json
 import logging
 import os
 import os.path as osp
+import queue
 import random as rn
 import re
 import subprocess
 import sys
+import threading
 import time
-from multiprocessing import Process, Queue
+from multiprocessing import Pool
 
 import numpy as np
 from PIL import Image
@@ -40,6 +50,7 @@ from arap_flow_amd import pipeline          # noqa: E402
 orgcolor, orgmask = "orgRGB", "orgMasks"                              # para_gen.py:18-26
 color_dir, mask_dir, constraints_dir = "inpRGB", "inpMasks", "tmpCnstr"
 flow_dir, wrgb_dir, wMask_dir = "Flow", "wRGB", "wMasks"
+CPP_BIN = osp.join(HERE, "arap_flow_amd", "bin", "arap_deform")
 
 
 def run_matching(flags, p, seq, stem):
@@ -86,29 +97,211 @@ def cleanup(p):
             os.remove(p[k])
 
 
-def do_arap(flags, paths, bgs, gpu, gpu_queue, arap_seg_paths):
-    """para_gen.py:178-214: one child per GPU; list file -> arap binary; flatten; background"""
-    os.makedirs("tmp", exist_ok=True)
-    fn = osp.abspath("tmp/gpu-%d_%s.txt" % (gpu, str(time.time()).replace(".", "_")))
-    print("GPU ", gpu, " ", len(paths), " files")
-    try:
-        open(fn, "w").write("\n".join(paths))
-        cmd = flags.arap_bin.split() + [fn]
-        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(gpu))           # reference: CUDA_VISIBLE_DEVICES (:190)
-        status = subprocess.call(cmd, env=env)
-        assert status == 0, "ARAP exited with code %d. The command was \n%s" % (status, " ".join(cmd))
-    finally:
-        os.remove(fn)
-    if len(arap_seg_paths) > 0:
-        paths = pipeline.flatten(arap_seg_paths)
-    for path, bg in zip(paths, bgs):
-        if bg is None:
-            continue
-        pt, mk = path.split(" ")[-2:]
+# ----------------------------------------------------------------------------------------------------------------
+# front end / back end of one frame pair: run in the --jobs pool
+# ----------------------------------------------------------------------------------------------------------------
+def prepare_pair(args):
+    """para_gen.py:447-556 for one pair: everything up to its list-file line(s).  Returns None when the pair is
+    dropped (no mask, no valid constraint), else dict(arap_path, seg_paths or None, bg)."""
+    flags, p, bgpath = args
+    p = dict(p)
+    seq, stem = p.pop("_seq"), p.pop("_stem")
+    arap_path = pipeline.make_arap_path(p)
+    for k in p:
+        os.makedirs(osp.dirname(p[k]), exist_ok=True)
+    im1, mk1, im2, mk2 = preprocess(p, flags.size)
+    if not has_mask(p["msk1_org"], p["msk2_org"]):
+        cleanup(p)
+        return None
+    run_matching(flags, p, seq, stem)
+    cstr_lines = open(p["cstr_tmp"]).read().splitlines()
+    cstrs, valids = pipeline.filter_matches(cstr_lines, mk1, mk2)
+    pipeline.write_constraints(p["cstr_tmp"], cstrs)
+    if len(cstrs) == 0:
+        cleanup(p)
+        return None
+    bgim = None
+    if bgpath is not None:
+        try:
+            bgim = np.array(Image.open(bgpath))
+            if not (bgim.ndim == 3 and bgim.shape[2] == 3):
+                bgim = None
+        except Exception:
+            bgim = None
+    if bgim is not None:
+        bgim = pipeline.fit_bg(bgim, im1, rng=rn.Random(hash((seq, stem)) & 0xffffffff))
+        out1 = pipeline.add_bg(im1, mk1, bgim)
+    else:
+        out1 = im1
+    Image.fromarray(out1).save(p["rgb1_gen"])
+    seg_paths = None
+    if not flags.multseg:
+        mask = np.zeros_like(mk1, dtype=np.uint8)
+        mask[mk1 == 0] = pipeline.ARAP_BG                                      # :514-517
+        Image.fromarray(mask).save(p["msk1_gen"])
+    else:
+        seg_paths = []
+        for s, mask in pipeline.split_segments(mk1, valids):                   # :518-540
+            p_ = pipeline.replace_ext(p, s, keep_orgs=["rgb1_gen", "cstr_tmp"])
+            Image.fromarray(mask).save(p_["msk1_gen"])
+            seg_paths.append(pipeline.make_arap_path(p_))
+    return dict(arap_path=arap_path, seg_paths=seg_paths, bg=bgim)
+
+
+def finish_frame(args):
+    """para_gen.py:202-212 for one frame whose solve(s) are done: flatten the segments, composite the background"""
+    arap_path, seg_paths, bg = args
+    if seg_paths is not None:
+        pipeline.flatten([(arap_path, seg_paths)])
+    if bg is not None:
+        pt, mk = arap_path.split(" ")[-2:]
         im = np.array(Image.open(pt).convert("RGB"))
         m = np.array(Image.open(mk))
         Image.fromarray(pipeline.add_bg(im, m, bg)).save(pt)
-    gpu_queue.put(gpu)
+    return arap_path
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GPU side: one worker per GPU id, lines to whichever has room
+# ----------------------------------------------------------------------------------------------------------------
+class GpuWorkers:
+    """The reference's GPU queue (para_gen.py:441-445,560-567) at line granularity.  `serve`: one persistent
+    `arap_bin --serve` child per GPU; `batch`: one `arap_bin listfile` child per hand-out of up to `narap` lines."""
+
+    def __init__(self, arap_bin, gpus, narap, serve, on_done):
+        self.cmd, self.narap, self.serve, self.on_done = arap_bin.split(), max(1, int(narap)), serve, on_done
+        self.lines = queue.Queue()
+        self.error = None
+        self.batches = []                      # solves per GPU launch (serve) / per child (batch)
+        self.threads, self.procs = [], []
+        self.t_ready = None
+        for g in gpus:
+            t = threading.Thread(target=self._serve_loop if serve else self._batch_loop, args=(g,), daemon=True)
+            t.start()
+            self.threads.append(t)
+
+    def put(self, line):
+        self.lines.put(line)
+
+    def close(self):
+        for _ in self.threads:
+            self.lines.put(None)
+
+    def join(self):
+        for t in self.threads:
+            while t.is_alive():
+                t.join(0.2)
+                self.check()
+        self.check()
+
+    def check(self):
+        if self.error is not None:
+            for p in self.procs:
+                if p.poll() is None:
+                    p.kill()
+            raise AssertionError(self.error)
+
+    def _fail(self, msg):
+        if self.error is None:
+            self.error = msg
+
+    def _env(self, gpu):
+        return dict(os.environ, HIP_VISIBLE_DEVICES=str(gpu))                  # reference: CUDA_VISIBLE_DEVICES (:190)
+
+    # -- persistent worker -----------------------------------------------------------------------------------
+    def _serve_loop(self, gpu):
+        try:
+            proc = subprocess.Popen(self.cmd + ["--serve"], env=self._env(gpu), stdin=subprocess.PIPE,
+                                    stdout=subprocess.PIPE, text=True, bufsize=1)
+        except OSError as e:
+            self._fail("cannot start %s: %s" % (" ".join(self.cmd), e))
+            return
+        self.procs.append(proc)
+        room = threading.Semaphore(self.narap)
+        outstanding = [0]
+        lock = threading.Lock()
+
+        def reader():
+            for ln in proc.stdout:
+                ln = ln.rstrip("\n")
+                if ln.startswith("Done "):
+                    with lock:
+                        outstanding[0] -= 1
+                    room.release()
+                    self.on_done(ln[5:])
+                elif ln.startswith("Batch "):
+                    self.batches.append(int(ln[6:]))
+                elif ln == "Ready":
+                    if self.t_ready is None:
+                        self.t_ready = time.time()
+                elif ln and ln != "Saved":
+                    print(ln)
+            rc = proc.wait()
+            with lock:
+                left = outstanding[0]
+            if rc != 0 or left != 0:
+                self._fail("ARAP worker on GPU %d exited with code %d, %d solves unfinished. The command was \n%s"
+                           % (gpu, rc, left, " ".join(self.cmd + ["--serve"])))
+            room.release()                                                      # never leave the feeder blocked
+
+        rt = threading.Thread(target=reader, daemon=True)
+        rt.start()
+        while self.error is None:
+            room.acquire()                                                      # a free place on this GPU first ...
+            if proc.poll() is not None:
+                break
+            line = self.lines.get()                                             # ... then the next line, whoever it is
+            if line is None:
+                break
+            with lock:
+                outstanding[0] += 1
+            try:
+                proc.stdin.write(line + "\n")
+                proc.stdin.flush()
+            except (BrokenPipeError, OSError):
+                self._fail("ARAP worker on GPU %d closed its input" % gpu)
+                break
+        try:
+            proc.stdin.close()
+        except OSError:
+            pass
+        rt.join()
+
+    # -- one child per hand-out (any executable with arap_deform's argv contract) -------------------------------
+    def _batch_loop(self, gpu):
+        os.makedirs("tmp", exist_ok=True)
+        while self.error is None:
+            line = self.lines.get()
+            if line is None:
+                return
+            batch, last = [line], False
+            while len(batch) < self.narap:
+                try:
+                    nxt = self.lines.get(timeout=0.05)
+                except queue.Empty:
+                    break
+                if nxt is None:
+                    last = True
+                    break
+                batch.append(nxt)
+            fn = osp.abspath("tmp/gpu-%d_%s.txt" % (gpu, str(time.time()).replace(".", "_")))
+            print("GPU ", gpu, " ", len(batch), " files")
+            try:
+                open(fn, "w").write("\n".join(batch))
+                status = subprocess.call(self.cmd + [fn], env=self._env(gpu))
+            except OSError as e:
+                status = "not started (%s)" % e
+            finally:
+                if osp.exists(fn):
+                    os.remove(fn)
+            if status != 0:
+                self._fail("ARAP exited with code %s. The command was \n%s" % (status, " ".join(self.cmd + [fn])))
+                return
+            self.batches.append(len(batch))
+            for ln in batch:
+                self.on_done(ln.split(" ")[3])
+            if last:
+                return
 
 
 def scan(flags, input_root, output_root):
@@ -144,91 +337,88 @@ def scan(flags, input_root, output_root):
 
 
 def main(flags):
+    t_start = time.time()
     input_root, output_root = flags.input.rstrip(osp.sep), flags.output.rstrip(osp.sep)
     bg_paths = []
     if flags.bg_dir:
         for root, _, files in os.walk(flags.bg_dir):
             bg_paths += [osp.join(root, f) for f in files if f.upper().endswith((".PNG", ".JPG", ".JPEG"))]
-    tmp_paths = []
     all_paths = scan(flags, input_root, output_root)
     print("Scanning data to be processed\t\t%d files [Done]" % len(all_paths))
-    lmdb_paths, arap_paths, arap_seg_paths, bgs, procs = [], [], [], [], {}
-    gpu_queue = Queue(len(flags.gpu))
-    for g in flags.gpu:
-        gpu_queue.put(g)
-
-    def dispatch(block):
-        nonlocal arap_paths, arap_seg_paths, bgs
-        if not arap_paths or (gpu_queue.empty() and not block):
-            return
-        gpu = gpu_queue.get()
-        proc = Process(target=do_arap, args=(flags, arap_paths, bgs, gpu, gpu_queue, arap_seg_paths))
-        proc.start()
-        procs.setdefault(gpu, []).append(proc)
-        arap_paths, arap_seg_paths, bgs = [], [], []
-
-    for i, p in enumerate(all_paths):
-        print("%.3f%%" % (float(i) * 100 / len(all_paths)))
-        seq, stem = p.pop("_seq"), p.pop("_stem")
-        arap_path = pipeline.make_arap_path(p)
-        ap = arap_path.split(" ")
+    os.makedirs(output_root, exist_ok=True)
+    lmdb_paths = []
+    for p in all_paths:
+        q = {k: v for k, v in p.items() if not k.startswith("_")}
+        ap = pipeline.make_arap_path(q).split(" ")
         lmdb_paths.append(" ".join([ap[0], ap[4], ap[3]]))
-        for k in p:
-            os.makedirs(osp.dirname(p[k]), exist_ok=True)
-        im1, mk1, im2, mk2 = preprocess(p, flags.size)
-        if not has_mask(p["msk1_org"], p["msk2_org"]):
-            cleanup(p)
+
+    # backgrounds: drawn without replacement until the list is used up, then refilled (para_gen.py:484-499)
+    tmp_paths, picks = [], []
+    for _ in all_paths:
+        if not bg_paths:
+            picks.append(None)
             continue
-        run_matching(flags, p, seq, stem)
-        cstr_lines = open(p["cstr_tmp"]).read().splitlines()
-        cstrs, valids = pipeline.filter_matches(cstr_lines, mk1, mk2)
-        pipeline.write_constraints(p["cstr_tmp"], cstrs)
-        if len(cstrs) == 0:
-            cleanup(p)
-            continue
-        bgim = None
-        while bg_paths:
-            if len(tmp_paths) == 0:
-                tmp_paths = sorted(bg_paths[:])
-            bgpath = rn.choice(tmp_paths)
-            tmp_paths.remove(bgpath)
-            try:
-                bgim = np.array(Image.open(bgpath))
-                if bgim.ndim == 3 and bgim.shape[2] == 3:
-                    break
-            except Exception:
-                pass
-            bg_paths.remove(bgpath)
-            bgim = None
-        if bgim is not None:
-            bgim = pipeline.fit_bg(bgim, im1)
-            out1 = pipeline.add_bg(im1, mk1, bgim)
-        else:
-            out1 = im1
-        bgs.append(bgim)
-        Image.fromarray(out1).save(p["rgb1_gen"])
-        seg_paths = None
-        if not flags.multseg:
-            mask = np.zeros_like(mk1, dtype=np.uint8)
-            mask[mk1 == 0] = pipeline.ARAP_BG                                      # :514-517
-            Image.fromarray(mask).save(p["msk1_gen"])
-        else:
-            seg_paths = []
-            for s, mask in pipeline.split_segments(mk1, valids):                   # :518-540
-                p_ = pipeline.replace_ext(p, s, keep_orgs=["rgb1_gen", "cstr_tmp"])
-                Image.fromarray(mask).save(p_["msk1_gen"])
-                seg_paths.append(pipeline.make_arap_path(p_))
-            arap_seg_paths.append((arap_path, seg_paths))
-        arap_paths += [arap_path] if seg_paths is None else seg_paths
-        dispatch(block=False)                                                      # :560-567
-    while arap_paths:
-        dispatch(block=True)
-    for lst in procs.values():
-        for proc in lst:
-            proc.join()
-            assert proc.exitcode == 0, "ARAP worker failed"
+        if not tmp_paths:
+            tmp_paths = sorted(bg_paths[:])
+        bgpath = rn.choice(tmp_paths)
+        tmp_paths.remove(bgpath)
+        picks.append(bgpath)
+
+    serve = flags.worker == "serve" or (flags.worker == "auto" and osp.abspath(flags.arap_bin.split()[0]) == CPP_BIN)
+    pool = Pool(processes=max(1, flags.jobs))          # (forked before any thread exists)
+    frames = {}                                        # flow path of a solve -> its frame record
+    posts, lock = [], threading.Lock()
+    counts = dict(solves_done=0, frames_done=0)
+
+    def on_done(flow_path):                            # a worker thread: one solve finished
+        with lock:
+            rec = frames.pop(flow_path)
+            counts["solves_done"] += 1
+            rec["left"] -= 1
+            if rec["left"] > 0:
+                return
+            counts["frames_done"] += 1
+            posts.append(pool.apply_async(finish_frame, ((rec["arap_path"], rec["seg_paths"], rec["bg"]),)))
+
+    workers = GpuWorkers(flags.arap_bin, flags.gpu, flags.narap, serve, on_done)
+    n_solves = n_frames = 0
+    try:
+        jobs = ((flags, p, bg) for p, bg in zip(all_paths, picks))
+        for i, res in enumerate(pool.imap(prepare_pair, jobs, chunksize=1)):
+            print("%.3f%%" % (float(i) * 100 / len(all_paths)))
+            workers.check()
+            if res is None:
+                continue
+            lines = [res["arap_path"]] if res["seg_paths"] is None else res["seg_paths"]
+            if not lines:
+                continue
+            rec = dict(arap_path=res["arap_path"], seg_paths=res["seg_paths"], bg=res["bg"], left=len(lines))
+            with lock:
+                for ln in lines:
+                    frames[ln.split(" ")[3]] = rec
+            for ln in lines:
+                workers.put(ln)
+            n_solves += len(lines)
+            n_frames += 1
+        workers.close()
+        workers.join()
+        for r in posts:
+            r.get()
+    finally:
+        pool.terminate()
+        for p in workers.procs:
+            if p.poll() is None:
+                p.kill()
     out_paths = [ln for ln in lmdb_paths if all(osp.exists(q) for q in ln.split(" "))]   # :588-603
     open(osp.join(output_root, "all_files.list"), "w").write("\n".join(out_paths))
+    dt = time.time() - t_start
+    stats = dict(pairs=len(all_paths), frames=n_frames, solves=n_solves, seconds=dt,
+                 seconds_since_workers_ready=(time.time() - workers.t_ready) if workers.t_ready else None,
+                 gpus=list(flags.gpu), worker="serve" if serve else "batch", jobs=flags.jobs, narap=flags.narap,
+                 batches=workers.batches,
+                 mean_batch=(float(np.mean(workers.batches)) if workers.batches else 0.0))
+    open(osp.join(output_root, "arap_stats.json"), "w").write(json.dumps(stats))
+    print("Finished: %d frames (%d solves) in %.2f s, mean batch %.1f" % (n_frames, n_solves, dt, stats["mean_batch"]))
     return out_paths
 
 
@@ -245,16 +435,24 @@ def parse(argv=None):
                         help="if each object segment is treated separately")
     parser.add_argument("--resume", action="store_true", default=False,
                         help="To skip the images that have *.flo finished.")
-    # (reference default: 7.  A child here costs ~0.4 s to start and solves 8 854x480 frames per 0.4 s launch, so
-    #  larger hand-outs keep the GPUs busy; any value works.)
+    # reference default: 7 (and never read there).  Here: the most list lines one GPU holds at a time -- enough for the
+    # batch being solved, the one being uploaded and the one being assembled (8 854x480 frames or ~21 segments each).
     parser.add_argument("--narap", type=int, default=64, help="Number of buffered files to be run by ARAP on gpu")
     parser.add_argument("--size", nargs=2, default=None,
                         help="2-tuple of [width] [space] [height] to which all images are resized.")
     parser.add_argument("--fd", type=int, default=1, help="distance between the 2 frames, default=1")
-    cpp_bin = osp.join(HERE, "arap_flow_amd", "bin", "arap_deform")
-    parser.add_argument("--arap_bin", default=cpp_bin if osp.exists(cpp_bin) else "%s %s" % (sys.executable, osp.join(HERE, "arap_deform.py")),
+    parser.add_argument("--arap_bin", default=CPP_BIN if osp.exists(CPP_BIN) else "%s %s" % (sys.executable, osp.join(HERE, "arap_deform.py")),
                         help="ARAP executable (argv contract of arap_deform), default: this repo's C++ driver "
                              "arap_flow_amd/bin/arap_deform when it is built, else arap_deform.py")
+    parser.add_argument("--worker", choices=["auto", "serve", "batch"], default="auto",
+                        help="serve: one persistent `arap_bin --serve` per GPU (this repo's C++ driver); batch: one "
+                             "`arap_bin listfile` child per hand-out; auto: serve for this repo's driver")
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    parser.add_argument("--jobs", type=int, default=max(1, min(12, ncpu - 2)),
+                        help="worker processes for the per-pair front end and back end")
     parser.add_argument("--dm_bin", default=None, help="Path to the deep matching binary")
     parser.add_argument("--matches", default=None, help="directory of precomputed matches (instead of --dm_bin)")
     parser.add_argument("--bg_dir", default=None, help="directory of background images")

@@ -41,6 +41,52 @@ VARIANTS = [
 ]
 
 
+def frame_schedule(mask_red, cons, A0, numIter=19, nIter=8, lIter=400):
+    """the arap_deform schedule (CombinedSolverBase.h:99-120) from Python over oracle.solve, product arithmetic, with
+    a chosen initial Angle image (oracle.frame itself always starts from Angle = 0, CombinedSolver.h:207-221)"""
+    H, W = mask_red.shape
+    ys, xs = np.mgrid[0:H, 0:W]
+    U = np.stack([xs, ys], -1).astype(np.float32)
+    O, A = U.copy(), A0.astype(np.float32)
+    M = mask_red.astype(np.float32)
+    allc = np.concatenate([np.asarray(cons, np.int32).reshape(-1, 4), orc.border_pins(W, H)])
+    wf, wr = np.sqrt(np.float32(100.0)), np.sqrt(np.float32(0.01))
+    costs = None
+    for i in range(numIter):
+        Cn = orc.constraint_image(mask_red, allc, np.float32(i + 1) / np.float32(numIter))
+        O, A, costs = orc.solve(O, A, U, Cn, M, wf, wr, nIter, lIter, dtype=np.float32, mode=1, trig=1)
+    return O, A, costs
+
+
+def perturbed_starts(cat, flows_ref, nseeds=6, amp=1e-6):
+    """How far does a perturbation far below anything physical move the answer?  Same arithmetic as the product, the
+    initial Angle image N(0, amp^2) rad instead of exactly 0 (amp = 1e-6 rad: 1e-4 px over a 100 px lever)."""
+    gold = cat["golden_flow"]
+    act = cat["mask_red"] == 0
+    H, W = act.shape
+    # sanity: zero perturbation reproduces oracle.frame bit for bit
+    O0, A0, c0 = frame_schedule(cat["mask_red"], cat["constraints"], np.zeros((H, W), np.float32), numIter=2, nIter=2, lIter=30)
+    Of, Af, cf = orc.frame(cat["mask_red"], cat["constraints"], numIter=2, nIterations=2, lIterations=30, dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(O0, Of) and np.array_equal(A0, Af)
+    rows = {}
+    for sd in range(nseeds):
+        rng = np.random.default_rng(4242 + sd)
+        A_init = (rng.normal(size=(H, W)) * amp).astype(np.float32) * act
+        t = time.time()
+        O, A, costs = frame_schedule(cat["mask_red"], cat["constraints"], A_init)
+        flow = orc.flow_from_offset(O)
+        err = np.linalg.norm(flow - gold, axis=-1)[act]
+        rows["seed%d" % sd] = {"initial_angle_sigma_rad": amp, "final_cost": float(costs[-1]),
+                               "rel_l2_vs_golden": float(helpers.rel_l2(flow[act], gold[act])),
+                               "rel_l2_vs_unperturbed_product": float(helpers.rel_l2(flow[act], flows_ref[act])),
+                               "median_px_vs_golden": float(np.median(err)),
+                               "max_handle_px_vs_golden": max(float(np.abs(flow[y1, x1] - gold[y1, x1]).max())
+                                                              for x1, y1, _, _ in cat["constraints"]),
+                               "neg_det_quads": helpers.neg_det_quads(flow, act), "seconds": round(time.time() - t, 1)}
+        print("perturbed", sd, json.dumps(rows["seed%d" % sd]), flush=True)
+    return rows
+
+
 def main():
     cat = helpers.load_cat512(HERE)
     gold = cat["golden_flow"]
@@ -64,13 +110,14 @@ def main():
     orc.use_variant(None)
     names = list(flows)
     mutual = {a: {b: float(helpers.rel_l2(flows[a][act], flows[b][act])) for b in names if b != a} for a in names}
-    out = {"fixture": "tests/golden/cat512 (= ARAP/deformation/cat512_i{RGB,Msk}.png, cat512_iCstr.txt; golden "
+    pert = perturbed_starts(cat, flows["f32_sum64_spec_fma"])
+    out = {"perturbed_starts_product_arithmetic": pert, "fixture": "tests/golden/cat512 (= ARAP/deformation/cat512_i{RGB,Msk}.png, cat512_iCstr.txt; golden "
                       "ARAP/warping/cat512_iFlo.flo), schedule 19/8/400",
            "golden_neg_det_quads": helpers.neg_det_quads(gold, act), "variants": rows, "mutual_rel_l2": mutual,
            "product_variant": "f32_sum64_spec_fma"}
     with open(os.path.join(HERE, "t4_variants.json"), "w") as f:
         json.dump(out, f, indent=1)
-    costs = [r["final_cost"] for r in rows.values()]
+    costs = [r["final_cost"] for r in rows.values()] + [r["final_cost"] for r in pert.values()]
     print("cost range %.3f .. %.3f" % (min(costs), max(costs)))
 
 

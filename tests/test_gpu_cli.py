@@ -166,7 +166,11 @@ def test_bench_contract_json_line(tmp_path):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] in ("hbm", "valu_issue+group_wait") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    for k in ("hbm_frac_by_counters", "valu_issue_frac", "wait_frac"):     # null unless a matching profiles/ record exists
+        assert k in r, k
+    assert d["parity_check"]["bit_equal"] is True                          # the timed work is the verified work
+    assert d["per_rank_ms_per_step"] and d["world_size_seen"] == 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -193,6 +197,7 @@ def test_bench_two_ranks_under_torch_distributed_run(tmp_path):
     assert d["config"]["frames_per_gpu_per_step"] == 2
     assert abs(d["value"] - 2 * 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # all ranks' frames / max time
     assert "roofline" in d and "cpu_baseline" not in d
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["world_size_seen"] == 2
 
 
 def test_resident_kernel_without_the_xcd_fast_paths(tmp_path):
@@ -250,3 +255,34 @@ def test_resident_failure_falls_back_to_two_kernel_path(tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fallback ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
     assert "Falling back to the two-kernel path" in r.stderr
+
+
+def test_real_group_wait_timeout_and_recovery(tmp_path):
+    """ARAPOPT_FORCE_RES_FAIL=2 leaves ONE workgroup of the first group out of the first resident launch: the rest of
+    that group spins in a real group wait until the bounded spin gives up (arap_resident.h: group_sum) and sets the
+    error word.  The solver redoes the schedule on the two-kernel path (oracle's bits), pauses the resident path for a
+    few solve calls and then takes it again (the failure is not sticky)."""
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from arap_flow_amd import opt, synth\n"
+        "from oracle import oracle as orc\n"
+        "st = opt.State()\n"
+        "f = synth.make_frame(320, 200, seed=3)\n"
+        "fs = opt.FrameSolver(st, 320, 200, batch=2)\n"
+        "fs.set_frame(0, f['mask_red'], f['constraints']); fs.set_frame(1, f['mask_red'], f['constraints'])\n"
+        "O, A, c = orc.frame(f['mask_red'], f['constraints'], numIter=2, nIterations=2, lIterations=30, dtype=np.float32, mode=1, trig=1)\n"
+        "fs.solve(2, 2, 2, 30); r = fs.results(0, want_rgb=False)\n"
+        "assert np.array_equal(r['offset'], O) and np.array_equal(r['angle'], A)\n"
+        "assert st.lib.ArapFlow_ResidentFailed(st.handle) == 1\n"
+        "n0 = fs.stats()['resident_launches']\n"
+        "for k in range(8):\n"                      # the pause: two-kernel path, no resident launches
+        "    fs.solve(2, 2, 2, 30)\n"
+        "assert fs.stats()['resident_launches'] == n0, (n0, fs.stats())\n"
+        "fs.solve(2, 2, 2, 30); r = fs.results(1, want_rgb=False)\n"     # pause over: resident again, same bits
+        "assert fs.stats()['resident_launches'] > n0\n"
+        "assert np.array_equal(r['offset'], O) and np.array_equal(r['angle'], A)\n"
+        "print('timeout ok')\n" % ROOT)
+    env = dict(os.environ, ARAPOPT_FORCE_RES_FAIL="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "timeout ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stderr.count("gave up at a group wait") == 1

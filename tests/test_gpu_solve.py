@@ -461,3 +461,47 @@ def test_profiled_solve_records_cost_per_gn_iteration(gpu_state, oracle):
     _, _, costs = oracle.solve(pb["O"], pb["A"], pb["U"], pb["C"], pb["M"], 10.0, 0.1, 3, 25, dtype=np.float32, mode=1, trig=1)
     recs = outs[1][1]
     assert len(recs) == 4 and [c for c, _ in recs] == list(costs) and all(ms >= 0 for _, ms in recs)
+
+
+def test_drop_in_step_sees_mask_and_urshape_changed_in_place(gpu_state, oracle):
+    """Opt.h:58-66 lets the caller change the parameters between Opt_ProblemInit and the Opt_ProblemSteps and the
+    reference re-reads them at every step (solverGPUGaussNewton.t:960,1026).  Changing the CONTENTS of Mask in place
+    (same buffer: new tiles become active, others inactive) between two Steps must give what the oracle gives stepping
+    with the new mask; so must turning UrShape into a generic shape (the resident kernel no longer applies)."""
+    W, H = 300, 150
+    pb = helpers.random_problem(W, H, seed=91, generic_urshape=False, mask_frac=0.0, ncons=80)
+    M1 = np.full((H, W), 255.0, np.float32); M1[20:90, 30:170] = 0.0           # active block in the upper left
+    M2 = np.full((H, W), 255.0, np.float32); M2[60:140, 120:290] = 0.0         # moves: new tiles active, old ones not
+    dev = {k: torch.from_numpy(pb[k].copy()).cuda() for k in "OAUC"}
+    dev["M"] = torch.from_numpy(M1.copy()).cuda()
+    s = opt.OptSolver(gpu_state, (W, H))
+    pp = opt.NamedParameters()
+    for n, k in [("Offset", "O"), ("Angle", "A"), ("UrShape", "U"), ("Constraints", "C"), ("Mask", "M")]:
+        pp.set(n, dev[k])
+    pp.set("w_fitSqrt", 10.0); pp.set("w_regSqrt", 0.1)
+    sp = opt.NamedParameters()
+    sp.set("nIterations", 3); sp.set("lIterations", 30)
+    s.set_solver_parameters(sp)
+    s.init(pp)
+    assert s.step(pp) == 1
+    n_res = s.resident_launches()
+    assert n_res > 0
+    O1, A1, c1 = oracle.solve(pb["O"], pb["A"], pb["U"], pb["C"], M1, 10.0, 0.1, 1, 30, dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(dev["O"].cpu().numpy(), O1) and np.array_equal(dev["A"].cpu().numpy(), A1)
+    dev["M"].copy_(torch.from_numpy(M2))                                      # in place: same device pointer
+    torch.cuda.synchronize()
+    assert s.step(pp) == 1
+    assert s.resident_launches() > n_res                                      # still the resident kernel, new tile list
+    O2, A2, c2 = oracle.solve(O1, A1, pb["U"], pb["C"], M2, 10.0, 0.1, 1, 30, dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(dev["O"].cpu().numpy(), O2) and np.array_equal(dev["A"].cpu().numpy(), A2)
+    assert s.current_cost() == c2[-1]
+    # UrShape becomes generic, in place: the step must leave the resident kernel and still match
+    U3 = pb["U"] + np.random.default_rng(5).normal(size=pb["U"].shape).astype(np.float32) * 0.2
+    dev["U"].copy_(torch.from_numpy(U3))
+    torch.cuda.synchronize()
+    n_res = s.resident_launches()
+    assert s.step(pp) == 1 and s.resident_launches() == n_res
+    O3, A3, c3 = oracle.solve(O2, A2, U3, pb["C"], M2, 10.0, 0.1, 1, 30, dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(dev["O"].cpu().numpy(), O3) and np.array_equal(dev["A"].cpu().numpy(), A3)
+    assert s.step(pp) == 0
+    s.close()

@@ -158,3 +158,46 @@ def test_resident_deal_packs_narrow_and_wide_solves():
         need = np.maximum((tiles + 8) // 9, 1)
         assert n >= int(np.ceil(need.sum() / 512))                         # cannot beat the capacity bound ...
         assert n <= len(tiles)                                             # ... and never worse than one solve per launch
+
+
+def test_c_program_against_the_reference_header_links_with_the_library(tmp_path):
+    """A C file that includes the REFERENCE's own ARAP/API/release/include/Opt.h and calls its ten functions must
+    compile and link against libarapopt.so unchanged (the drop-in boundary).  Run here it gets NULL from
+    Opt_NewState (no HIP device, no CPU fallback) and stops there.  Skipped where /root/reference is absent."""
+    import subprocess
+    from arap_flow_amd import build
+    inc = "/root/reference/ARAP/API/release/include"
+    if not os.path.exists(os.path.join(inc, "Opt.h")):
+        pytest.skip("reference tree not present")
+    lib = build.build()
+    src = tmp_path / "dropin.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "Opt.h"
+int main(void)
+{
+    Opt_InitializationParameters ip = {0, 0, 0, 0};
+    Opt_State* st = Opt_NewState(ip);
+    if (!st) { printf("no state\n"); return 0; }
+    unsigned dims[2] = {64, 64};
+    int n = 2, l = 10;
+    void* params[7] = {0};
+    Opt_Problem* pr = Opt_ProblemDefine(st, "arap_plan.t", "gaussNewtonGPU");
+    Opt_Plan* pl = Opt_ProblemPlan(st, pr, dims);
+    Opt_SetSolverParameter(st, pl, "nIterations", &n);
+    Opt_SetSolverParameter(st, pl, "lIterations", &l);
+    Opt_ProblemInit(st, pl, params);
+    while (Opt_ProblemStep(st, pl, params)) {}
+    Opt_ProblemSolve(st, pl, params);
+    printf("%f\n", Opt_ProblemCurrentCost(st, pl));
+    Opt_PlanFree(st, pl);
+    Opt_ProblemDelete(st, pr);
+    return 0;
+}
+''')
+    exe = tmp_path / "dropin"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + inc, str(src), "-o", str(exe),
+                           "-L" + os.path.dirname(lib), "-larapopt", "-Wl,-rpath," + os.path.dirname(lib),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "no state" in r.stdout, r.stdout + r.stderr

@@ -119,3 +119,96 @@ def test_para_gen_scan_pairs_and_resume(tmp_path):
     os.makedirs(osp.dirname(e[0]["flow_gen"])); open(e[0]["flow_gen"], "w").close()
     flags.resume = True
     assert len(para_gen.scan(flags, str(inp), str(outp))) == 2          # --resume skips finished pairs
+
+
+def _tiny_tree(tmp_path, nframes=7, W=64, H=40, seqs=("a", "b")):
+    """DAVIS-shaped input tree with precomputed matches: nframes frames per sequence -> (nframes-1) pairs each"""
+    from arap_flow_amd import synth
+    inp, mdir = tmp_path / "in", tmp_path / "matches"
+    for si, seq in enumerate(seqs):
+        os.makedirs(inp / "orgRGB" / seq); os.makedirs(inp / "orgMasks" / seq); os.makedirs(mdir / seq)
+        fr = synth.make_frame(W, H, seed=20 + si, K=2)
+        for n in range(nframes):
+            Image.fromarray(fr["rgb"]).save(inp / "orgRGB" / seq / ("%05d.png" % n))
+            Image.fromarray(fr["labels"].astype(np.uint8)).save(inp / "orgMasks" / seq / ("%05d.png" % n))
+            (mdir / seq / ("%05d.txt" % n)).write_text("\n".join("%d %d %d %d 1.0 0" % tuple(c) for c in fr["constraints"]))
+    return inp, mdir
+
+
+FAKE_WORKER = r'''
+import sys, shutil
+# stand-in for an ARAP executable (no GPU): "solves" a line by writing the flow / warped files para_gen expects
+def solve(line):
+    rgb, msk, cst, flo, wrgb, wmsk = line.split()
+    import numpy as np
+    from PIL import Image
+    sys.path.insert(0, %r)
+    from arap_flow_amd import flo as F
+    m = np.array(Image.open(msk).convert("RGB"))[..., 0]
+    F.flow_write(flo, np.zeros(m.shape + (2,), np.float32))
+    shutil.copy(rgb, wrgb)
+    Image.fromarray(m == 0).save(wmsk)
+if sys.argv[1] == "--serve":
+    print("Ready", flush=True)
+    batch = []
+    for line in sys.stdin:
+        if FAIL_AFTER >= 0 and len(batch) >= FAIL_AFTER: sys.exit(3)
+        batch.append(line)
+        solve(line); print("Batch 1", flush=True); print("Done " + line.split()[3], flush=True)
+else:
+    lines = [l for l in open(sys.argv[1]).read().splitlines() if l.strip()]
+    if FAIL_AFTER >= 0: sys.exit(3)
+    for l in lines: solve(l)
+'''
+
+
+@pytest.mark.parametrize("worker,multseg", [("serve", False), ("serve", True), ("batch", True)])
+def test_para_gen_with_a_stand_in_worker(tmp_path, worker, multseg):
+    """para_gen's own machinery without a GPU: pool front end, one worker per GPU id fed over a pipe (serve) or one
+    child per hand-out of <= --narap lines (batch), completion tracking per segment, flatten, all_files.list, stats"""
+    sys.path.insert(0, ROOT)
+    import json
+    import para_gen
+    inp, mdir = _tiny_tree(tmp_path)
+    fake = tmp_path / "fake_arap.py"
+    fake.write_text("FAIL_AFTER = -1\n" + FAKE_WORKER % ROOT)
+    outp = tmp_path / "out"
+    argv = ["--input", str(inp), "--output", str(outp), "--gpu", "0", "1", "--matches", str(mdir), "--worker", worker,
+            "--arap_bin", "%s %s" % (sys.executable, fake), "--narap", "5", "--jobs", "2"] + (["--multseg"] if multseg else [])
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        out = para_gen.main(para_gen.parse(argv))
+    finally:
+        os.chdir(cwd)
+    assert len(out) == 12                                                   # 2 sequences x 6 pairs
+    st = json.load(open(outp / "arap_stats.json"))
+    assert st["frames"] == 12 and st["solves"] == (24 if multseg else 12) and st["worker"] == worker
+    assert sum(st["batches"]) == st["solves"] and max(st["batches"]) <= 5   # --narap bounds a hand-out
+    for ln in out:
+        assert all(osp.exists(q) for q in ln.split(" "))
+    if multseg:                                                             # per-segment files were merged and removed
+        assert not [f for f in os.listdir(outp / "Flow" / "a") if "_seg" in f]
+
+
+@pytest.mark.parametrize("worker", ["serve", "batch"])
+def test_para_gen_fails_promptly_when_the_arap_worker_dies(tmp_path, worker):
+    """a worker that exits non-zero must fail the run at once -- the reference hangs here (the GPU id never returns
+    to its queue, para_gen.py:193-214,560-567)"""
+    sys.path.insert(0, ROOT)
+    import time
+    import para_gen
+    inp, mdir = _tiny_tree(tmp_path, nframes=4, seqs=("a",))
+    fake = tmp_path / "fake_arap.py"
+    fake.write_text("FAIL_AFTER = 1\n" + FAKE_WORKER % ROOT)
+    argv = ["--input", str(inp), "--output", str(tmp_path / "out"), "--gpu", "0", "--matches", str(mdir), "--worker", worker,
+            "--arap_bin", "%s %s" % (sys.executable, fake), "--jobs", "2"]
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    t0 = time.time()
+    try:
+        with pytest.raises(AssertionError, match="exited with code 3"):
+            para_gen.main(para_gen.parse(argv))
+    finally:
+        os.chdir(cwd)
+    assert time.time() - t0 < 60

@@ -1,28 +1,106 @@
-"""End-to-end timing of the host programs on synthetic 854x480 PNG inputs (GPU): C++ arap_deform, Python arap_deform.py.
-   python tools/bench_hosts.py [frames]"""
-import os, sys, time, subprocess, tempfile
+"""End-to-end throughput of the host pipeline on synthetic DAVIS-shaped 854x480 inputs (GPU box):
+
+    python tools/bench_hosts.py [pairs] [--multseg] [--out JSON]
+
+  1. the real CLI: `para_gen.py --matches` over a synthetic input tree of `pairs` frame pairs (PNG frames, label masks,
+     precomputed match files) with the C++ driver as a persistent --serve worker: wall time from process start to
+     exit, time since the GPU worker was ready, batch sizes handed to the GPU (OUT/arap_stats.json);
+  2. the C++ driver and its Python twin on a list file of the same frames (process start to exit).
+One JSON record on stdout (and into --out): what profiles/r02_hosts*.json hold."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np
-from PIL import Image
-from arap_flow_amd import synth, pipeline
+import numpy as np                      # noqa: E402
+from PIL import Image                   # noqa: E402
+from arap_flow_amd import pipeline, synth   # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-d = tempfile.mkdtemp(prefix="arap_hosts_")
-lines = []
-for i in range(n):
-    f = synth.make_frame(854, 480, seed=i)
-    p = lambda s: os.path.join(d, "%03d_%s" % (i, s))
-    Image.fromarray(f["rgb"]).save(p("rgb.png"))
-    Image.fromarray(np.stack([f["mask_red"]] * 3, -1)).save(p("msk.png"))
-    pipeline.write_constraints(p("c.txt"), [tuple(c) for c in f["constraints"]])
-    lines.append(" ".join([p("rgb.png"), p("msk.png"), p("c.txt"), p("o.flo"), p("o_rgb.png"), p("o_msk.png")]))
-lst = os.path.join(d, "list.txt")
-open(lst, "w").write("\n".join(lines) + "\n")
-env = {k: v for k, v in os.environ.items() if k != "ARAP_PLAN"}
-for name, cmd in (("C++ bin/arap_deform", [os.path.join(ROOT, "arap_flow_amd", "bin", "arap_deform"), lst]),
-                  ("python arap_deform.py", [sys.executable, os.path.join(ROOT, "arap_deform.py"), lst])):
-    t = time.time()
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True)
-    dt = time.time() - t
-    print("%-24s rc %d  %d frames in %.2f s = %.2f frames/s  (%s)" % (name, r.returncode, n, dt, n / dt, (r.stdout + r.stderr).strip().splitlines()[-1][:80] if (r.stdout + r.stderr).strip() else ""))
+
+def make_tree(d, pairs, W, H, K):
+    """one two-frame sequence per pair (frame seed = pair index, DAVIS-shaped blob(s), lattice matches): both frames of
+    a pair carry the same labels so that para_gen's match filter (same label at both ends, para_gen.py:216-223) keeps
+    the synthetic matches"""
+    inp, mdir = os.path.join(d, "in"), os.path.join(d, "matches")
+    for n in range(pairs):
+        name = "seq%04d" % n
+        for sub in ("orgRGB", "orgMasks"):
+            os.makedirs(os.path.join(inp, sub, name))
+        os.makedirs(os.path.join(mdir, name))
+        f = synth.make_frame(W, H, seed=n, K=K, fd=1)
+        rgb, lab = Image.fromarray(f["rgb"]), Image.fromarray(f["labels"].astype(np.uint8))
+        for k in range(2):
+            rgb.save(os.path.join(inp, "orgRGB", name, "%05d.png" % k))
+            lab.save(os.path.join(inp, "orgMasks", name, "%05d.png" % k))
+        open(os.path.join(mdir, name, "00000.txt"), "w").write(
+            "\n".join("%d %d %d %d 1.0 0" % tuple(c) for c in f["constraints"]))
+    return inp, mdir
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("pairs", type=int, nargs="?", default=128)
+    ap.add_argument("--multseg", action="store_true")
+    ap.add_argument("--size", type=int, nargs=2, default=[854, 480])
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--skip-list-mode", action="store_true")
+    a = ap.parse_args()
+    W, H = a.size
+    d = tempfile.mkdtemp(prefix="arap_hosts_")
+    rec = {"pairs": a.pairs, "size": [W, H], "multseg": bool(a.multseg)}
+    try:
+        t = time.time()
+        inp, mdir = make_tree(d, a.pairs, W, H, 3 if a.multseg else 1)
+        rec["tree_seconds"] = time.time() - t
+        out = os.path.join(d, "out")
+        cmd = [sys.executable, os.path.join(ROOT, "para_gen.py"), "--input", inp, "--output", out, "--gpu", "0",
+               "--matches", mdir] + (["--multseg"] if a.multseg else [])
+        env = {k: v for k, v in os.environ.items() if k != "ARAP_PLAN"}
+        t = time.time()
+        r = subprocess.run(cmd, env=env, cwd=d, capture_output=True, text=True)
+        dt = time.time() - t
+        if r.returncode != 0:
+            print(r.stdout[-2000:], r.stderr[-2000:])
+            raise SystemExit("para_gen failed")
+        st = json.load(open(os.path.join(out, "arap_stats.json")))
+        done = len(open(os.path.join(out, "all_files.list")).read().splitlines())
+        rec["para_gen"] = {"frames": st["frames"], "solves": st["solves"], "listed": done, "wall_seconds": dt,
+                           "frames_per_s_wall": st["frames"] / dt,
+                           "frames_per_s_since_worker_ready": st["frames"] / st["seconds_since_workers_ready"]
+                           if st.get("seconds_since_workers_ready") else None,
+                           "mean_batch": st["mean_batch"], "batches": st["batches"], "jobs": st["jobs"],
+                           "narap": st["narap"], "worker": st["worker"]}
+        if not a.skip_list_mode:
+            n = min(a.pairs, 64)
+            lines = []
+            for i in range(n):
+                f = synth.make_frame(W, H, seed=i)
+                p = lambda s: os.path.join(d, "%03d_%s" % (i, s))          # noqa: E731
+                Image.fromarray(f["rgb"]).save(p("rgb.png"))
+                Image.fromarray(np.stack([f["mask_red"]] * 3, -1)).save(p("msk.png"))
+                pipeline.write_constraints(p("c.txt"), [tuple(c) for c in f["constraints"]])
+                lines.append(" ".join([p("rgb.png"), p("msk.png"), p("c.txt"), p("o.flo"), p("o_rgb.png"), p("o_msk.png")]))
+            lst = os.path.join(d, "list.txt")
+            open(lst, "w").write("\n".join(lines) + "\n")
+            for name, c in (("cpp_arap_deform_list", [os.path.join(ROOT, "arap_flow_amd", "bin", "arap_deform"), lst]),
+                            ("python_arap_deform_list", [sys.executable, os.path.join(ROOT, "arap_deform.py"), lst])):
+                t = time.time()
+                r = subprocess.run(c, env=env, capture_output=True, text=True)
+                dt = time.time() - t
+                rec[name] = {"rc": r.returncode, "frames": n, "wall_seconds": dt, "frames_per_s_wall": n / dt}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    s = json.dumps(rec)
+    print(s)
+    if a.out:
+        open(a.out, "w").write(s + "\n")
+
+
+if __name__ == "__main__":
+    main()
