@@ -69,23 +69,26 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Opt_ProblemInit analysis for the resident path of the drop-in API: which 64x4 tiles hold an active vertex,
-// and is UrShape the pixel grid on every active vertex (then d = U(c)-U(n) = -s on every valid edge, which is
+// Drop-in API, before every step: which 32x8 tiles (fixed grid; launch with 32x8 blocks, one per tile) hold an active
+// vertex, and is UrShape the pixel grid on every active vertex (then d = U(c)-U(n) = -s on every valid edge, which is
 // what arap_resident.h specialises on; the application always passes that grid, CombinedSolver.h:207-221).
-__global__ __launch_bounds__(TILE_X* TILE_Y) void k_analyse(PlanDev pd, int* not_grid)
+__global__ __launch_bounds__(256) void k_analyse(PlanDev pd, uint8_t* tile_active, int* not_grid)
 {
-    const VIdx v = vidx(pd);
-    const Slot sl = pd.slots[v.b];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    const Slot sl = pd.slots[0];
     int act = 0, bad = 0;
-    if (v.in && sl.M[v.i] == 0.0f) {
-        act = 1;
-        const float2 u = sl.U[v.i];
-        bad = !(u.x == (float)v.x && u.y == (float)v.y);
+    if (x < pd.W && y < pd.H) {
+        const int i = x + pd.W * y;
+        if (sl.M[i] == 0.0f) {
+            act = 1;
+            const float2 u = sl.U[i];
+            bad = !(u.x == (float)x && u.y == (float)y);
+        }
     }
     const int any = __syncthreads_or(act);
     const int anybad = __syncthreads_or(bad);
     if (threadIdx.x == 0 && threadIdx.y == 0) {
-        pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
+        tile_active[blockIdx.y * gridDim.x + blockIdx.x] = any ? 1 : 0;
         if (anybad) atomicOr(not_grid, 1);
     }
 }

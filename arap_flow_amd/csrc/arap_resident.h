@@ -6,9 +6,9 @@
 // workgroups empty).  Here every frame of the batch is solved by a GROUP of workgroups (256 threads, TWO
 // workgroups per CU so one computes while the other waits; the host sizes the group by the frame's
 // active tiles, ResWg below) that stays resident for all lIterations iterations:
-//   * r, delta, M^-1, flags and the transient Ap live in registers (9 tile slots of 64x4 vertices per
-//     workgroup, one vertex per lane per slot),
-//   * the search direction p and cos/sin(A) live in LDS as 66x6 halo'd tiles (the stencil reads
+//   * r, delta, M^-1, flags and the transient Ap live in registers (9 tile slots of 32x8 vertices per
+//     workgroup, one vertex per lane per slot; tiles start at each 8-row band's first active vertex),
+//   * the search direction p and cos/sin(A) live in LDS as 34x10 halo'd tiles (the stencil reads
 //     every neighbour from LDS, one tile slot ahead of the arithmetic; cells that are not active
 //     vertices are zero and invalid edges get a zero weight, so the phases are branch free),
 //   * per iteration the group exchanges only (a) two 16-byte partial sums per workgroup (all-gather
@@ -34,19 +34,27 @@ namespace arap {
 constexpr int RES_WGS = 512;             // workgroups per launch: TWO per CU of an MI355X (256 CUs), so that one
                                          // workgroup computes while its CU-mate (another frame's group) waits
 constexpr int RES_MAX_GROUPS = 16;       // most equal groups ARAPOPT_RES_GROUPS may force (experiments)
-constexpr int RES_THREADS = 256;         // 4 wavefronts = the 4 rows of a 64x4 tile, one per SIMD
+constexpr int RES_THREADS = 256;         // 4 wavefronts = 4 x 2 rows of a 32x8 tile, one per SIMD
 constexpr int RES_SLOTS = 9;             // tile slots per workgroup (register arrays, fully unrolled)
 constexpr int RES_TILES_PER_WG = RES_SLOTS;
-constexpr int RES_MAX_HALO = RES_TILES_PER_WG * 136;                 // 2 x 64 + 2 x 4 halo cells per tile
-constexpr int RES_HALO_PER_THREAD = (RES_MAX_HALO + RES_THREADS - 1) / RES_THREADS;   // 5
+// Tile of the resident kernel: 32 x 8 vertices, one vertex per lane: a wavefront holds two rows of 32 (lanes 0-31 and
+// 32-63), the four wavefronts the eight rows.  Tiles live in BANDS of 8 rows; within a band they start at the band's
+// first active vertex (any x, chosen by the host: ResDev::bandx0) and follow each other every 32 columns.  Against
+// 64 x 4 tiles on a fixed grid this cuts the tiles of a DAVIS-shaped blob by 12 % (432 instead of 494 at 854x480:
+// 7 tile slots per workgroup instead of 8-9, the phases are proportional to the slots) and the halo cells per tile
+// from 136 to 80.
+constexpr int RT_X = 32, RT_Y = 8;
+static_assert(RT_X * RT_Y == RES_THREADS && RT_Y == 2 * (RES_THREADS / 64), "one vertex per lane, two rows per wavefront");
+constexpr int RES_MAX_HALO = RES_TILES_PER_WG * (2 * RT_X + 2 * RT_Y);          // 80 halo cells per tile
+constexpr int RES_HALO_PER_THREAD = (RES_MAX_HALO + RES_THREADS - 1) / RES_THREADS;   // 3
 constexpr int RES_MAX_TILES = RES_WGS * RES_TILES_PER_WG;   // 4608 tiles (one group of 512 workgroups)
-constexpr int LROW = TILE_X + 2;         // 66
-constexpr int LROWS = TILE_Y + 2;        // 6
-constexpr int LPLANE = LROW * LROWS;     // 396 floats
+constexpr int LROW = RT_X + 2;           // 34
+constexpr int LROWS = RT_Y + 2;          // 10
+constexpr int LPLANE = LROW * LROWS;     // 340 floats
 constexpr int LTILE = 5 * LPLANE;        // float2 (px,py) plane | float2 (cos,sin) plane | float pa plane
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
                               + ((RES_MAX_HALO * 8 + 15) / 16) * 16   // halo list (u16), then the decoded halo table (uint2)
-                              + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (79.6 KB: 2 per CU)
+                              + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (67.4 KB: 2 per CU)
 static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two workgroups per CU");
 #ifndef RES_PAIR_SLOTS
 #define RES_PAIR_SLOTS 1      // slots of phase A the scheduler may interleave (register pressure vs latency hiding)
@@ -69,9 +77,11 @@ struct ResWg {
 };
 
 struct ResDev {
-    const int* tilelist;        // [batch][RES_MAX_TILES] linear tile index (ty * tilesX + tx) of active tiles
+    const int* tilelist;        // [batch][RES_MAX_TILES] origin vertex index (x0 + W y0) of the active tiles, band by band
     const int* ntiles;          // [batch]
-    const int* tilepos;         // [batch][tilesX * tilesY] position of a tile in its frame's list, -1 = inactive
+    const int* tilepos;         // [batch][rtX * rtY] position in the list of the k-th tile column of a band, -1 = inactive
+    const int* bandx0;          // [batch][rtY] x of the first tile of every 8-row band
+    int rtX, rtY;               // ceil(W / 32) tile columns at most per band, ceil(H / 8) bands
     unsigned long long* gran;   // [RES_GRAN_PER_LAUNCH]  {tag << 32 | 32 value bits}
     unsigned* err;              // [1] 0 = ok
     const ResWg* wgmap;         // [RES_WGS] of this launch
@@ -290,12 +300,16 @@ __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 do
 
 // grid = 512 workgroups (groups x wgs), block = 256, dynamic LDS = RES_LDS_BYTES (two workgroups per CU)
 //
-// LDS map: 9 halo'd tiles x {px,py,pa,cos,sin} (71 280 B); halo table (uint2 per halo cell, <= 1224; it
+// LDS map: 9 halo'd tiles x {px,py,pa,cos,sin} (61 200 B); halo table (uint2 per halo cell, <= 720; it
 // starts life as the u16 cell list); tile origins int2[9]; the 10-entry M^-1_O table; broadcast + reduction scratch.
 // Registers per lane: r(3) delta(3) Ap(3) M^-1_A M^-1_O flags for each of the 9 slots = 108 of 242.
-template <bool STAMPS>
+// NS = tile slots the loops run over (1 .. RES_SLOTS): the most tiles any workgroup of the LAUNCH holds (the host picks
+// the instantiation per launch, arapopt.hip: launch_resident).  The phases are fully unrolled and branch free over the
+// slots, so their length is proportional to NS: a launch whose solves need 7 tiles per workgroup runs the 7-slot kernel.
+template <bool STAMPS, int NS>
 __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, ResDev rd, int L)
 {
+    static_assert(NS >= 1 && NS <= RES_SLOTS, "slots");
     unsigned long long tA = 0, tS1 = 0, tB = 0, tS2 = 0, tU = 0, t0 = 0, t1 = 0;
 #define RES_STAMP(acc) do { if (STAMPS) { t1 = __builtin_amdgcn_s_memrealtime(); acc += t1 - t0; t0 = t1; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -317,7 +331,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     const int W = pd.W, H = pd.H;
     const size_t gb = (size_t)b * pd.N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wy = wave;                               // row inside the tile
+    const int lx = lane & (RT_X - 1), ly = (wave << 1) | (lane >> 5);     // this lane's vertex inside a tile
     unsigned short* hlist = (unsigned short*)(lds + RES_TILES_PER_WG * LTILE);    // [RES_MAX_HALO]
     int2* tbase = (int2*)((char*)hlist + ((RES_MAX_HALO * 8 + 15) / 16) * 16);    // [9] tile origin (x0, y0)
     float* moLUT = (float*)(tbase + RES_TILES_PER_WG + 1);                // [10] (+2 pad)
@@ -355,26 +369,26 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 
     // every cell of the halo'd tiles holds a finite value: cells outside the image or of unused slots are never
     // written below, and phase A multiplies (not selects) the contributions of invalid edges by zero
-    for (int c = tid; c < RES_TILES_PER_WG * LTILE; c += RES_THREADS) lds[c] = 0.f;
+    for (int c = tid; c < NS * LTILE; c += RES_THREADS) lds[c] = 0.f;
     __syncthreads();
 
-    float rx[RES_SLOTS], ry[RES_SLOTS], ra[RES_SLOTS];
-    float dx_[RES_SLOTS], dy_[RES_SLOTS], da_[RES_SLOTS];
-    float apx[RES_SLOTS], apy[RES_SLOTS], apa[RES_SLOTS];
-    float ma_[RES_SLOTS], mo_[RES_SLOTS];
-    unsigned fl[RES_SLOTS];
-    int ibase[RES_SLOTS];                              // SGPRs
-    const int loff = lane + W * wy;                    // this lane's vertex inside a tile: index = ibase + loff
+    float rx[NS], ry[NS], ra[NS];
+    float dx_[NS], dy_[NS], da_[NS];
+    float apx[NS], apy[NS], apa[NS];
+    float ma_[NS], mo_[NS];
+    unsigned fl[NS];
+    int ibase[NS];                                     // SGPRs
+    const int loff = lx + W * ly;                      // this lane's vertex inside a tile: index = ibase + loff
 
-    // LDS tile t: float2 P2[396] (px,py) | float2 CS[396] (cos,sin) | float PA[396]; cell = row*66 + col
-    const int cell = (wy + 1) * LROW + (lane + 1);
+    // LDS tile t: float2 P2[340] (px,py) | float2 CS[340] (cos,sin) | float PA[340]; cell = row*34 + col
+    const int cell = (ly + 1) * LROW + (lx + 1);
 #define TP2(T) ((float2*)(T))
 #define TCS(T) ((float2*)(T) + LPLANE)
 #define TPA(T) ((T) + 4 * LPLANE)
 
     // ---- prologue: load state, p0 and cos/sin with halos ------------------------------------------
 #pragma unroll
-    for (int j = 0; j < RES_SLOTS; ++j) {
+    for (int j = 0; j < NS; ++j) {
         const int k = j;                               // local tile
         const int gt = tfirst + k;                     // position in the frame's active-tile list
         rx[j] = ry[j] = ra[j] = 0.f; dx_[j] = dy_[j] = da_[j] = 0.f;
@@ -383,10 +397,9 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         float mA = 0.f;
         int x0 = -1, y0 = -1;
         if (k < tp) {
-            const int tile = tl[gt];
-            const int ty = tile / pd.tilesX, tx = tile - ty * pd.tilesX;
-            x0 = tx * TILE_X; y0 = ty * TILE_Y;
-            const int x = x0 + lane, y = y0 + wy;
+            const int org = tl[gt];
+            y0 = org / W; x0 = org - y0 * W;
+            const int x = x0 + lx, y = y0 + ly;
             float* T = lds + k * LTILE;
             if (x < W && y < H) {
                 const int i = x + W * y;
@@ -404,14 +417,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 }
                 // halo cells this thread is responsible for
                 int hi = -1, hc = 0;
-                if (wy == 0 && y0 > 0) { hi = i - W; hc = 0 * LROW + (lane + 1); }
-                if (wy == 3 && y + 1 < H) { hi = i + W; hc = 5 * LROW + (lane + 1); }
+                if (ly == 0 && y0 > 0) { hi = i - W; hc = 0 * LROW + (lx + 1); }
+                if (ly == RT_Y - 1 && y + 1 < H) { hi = i + W; hc = (RT_Y + 1) * LROW + (lx + 1); }
                 if (hi >= 0 && (pd.flags[gb + hi] & F_ACT)) {
                     TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
                 }
                 hi = -1;
-                if (lane == 0 && x0 > 0) { hi = i - 1; hc = (wy + 1) * LROW + 0; }
-                if (lane == 63 && x + 1 < W) { hi = i + 1; hc = (wy + 1) * LROW + 65; }
+                if (lx == 0 && x0 > 0) { hi = i - 1; hc = (ly + 1) * LROW + 0; }
+                if (lx == RT_X - 1 && x + 1 < W) { hi = i + 1; hc = (ly + 1) * LROW + (RT_X + 1); }
                 if (hi >= 0 && (pd.flags[gb + hi] & F_ACT)) {
                     TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
                 }
@@ -427,13 +440,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     __syncthreads();
     // ---- halo list: every halo cell whose adjacent interior vertex (this lane's) has the matching edge bit
 #pragma unroll
-    for (int j = 0; j < RES_SLOTS; ++j) {
+    for (int j = 0; j < NS; ++j) {
         const unsigned f = fl[j];
         mo_[j] = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)];      // M^-1 of the Offset components
-        if (wy == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lane + 1);
-        if (wy == 3 && (f & F_E2)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 5 * LROW + lane + 1);
-        if (lane == 0 && (f & F_E1)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (wy + 1) * LROW + 0);
-        if (lane == 63 && (f & F_E0)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (wy + 1) * LROW + 65);
+        if (ly == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lx + 1);
+        if (ly == RT_Y - 1 && (f & F_E2)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (RT_Y + 1) * LROW + lx + 1);
+        if (lx == 0 && (f & F_E1)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (ly + 1) * LROW + 0);
+        if (lx == RT_X - 1 && (f & F_E0)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (ly + 1) * LROW + RT_X + 1);
     }
     __syncthreads();
     const int nh = *nhalo;
@@ -456,7 +469,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 e[u].x = (unsigned)(gx + W * gy);
                 e[u].y = (unsigned)(k * (LTILE / 2) + rem) | ((unsigned)(k * LTILE + 4 * LPLANE + rem) << 16);
                 // which workgroup of the group owns that vertex (the even deal above)?  -> neighbour bitmap
-                const int pos = rd.tilepos[(size_t)b * pd.tilesX * pd.tilesY + (gy / TILE_Y) * pd.tilesX + gx / TILE_X];
+                // the tile that holds (gx, gy): band gy / 8, column (gx - first x of that band) / 32 (the halo vertex is
+                // active, so it is not left of its band's first tile)
+                const int band = gy / RT_Y;
+                const int kx = (gx - rd.bandx0[(size_t)b * rd.rtY + band]) / RT_X;
+                const int pos = rd.tilepos[((size_t)b * rd.rtY + band) * rd.rtX + (kx < 0 ? 0 : (kx < rd.rtX ? kx : rd.rtX - 1))];
                 const int nfull = textra * (tbase_n + 1);
                 const int owner = pos < nfull ? pos / (tbase_n + 1) : textra + (pos - nfull) / (tbase_n > 0 ? tbase_n : 1);
                 if (pos >= 0 && owner != rank) atomicOr(&nbits[(owner >> 5) & 15], 1u << (owner & 31));
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         __syncthreads();                             // every u16 entry has been read
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u)
-            if (tid + u * RES_THREADS < RES_MAX_HALO) htab[tid + u * RES_THREADS] = e[u];     // 5 x 256 > 1224 entries
+            if (tid + u * RES_THREADS < RES_MAX_HALO) htab[tid + u * RES_THREADS] = e[u];     // 3 x 256 > 720 entries
         // (each thread reads back only what it wrote: no barrier needed)
     }
     static_assert(RES_TILES_PER_WG * LTILE < 65536 && LTILE % 2 == 0, "halo table packs 16-bit cell offsets");
@@ -579,13 +596,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         RES_LOAD_A(0)
         RES_LOAD_B(0)
 #pragma unroll
-        for (int j = 0; j < RES_SLOTS; ++j) {
+        for (int j = 0; j < NS; ++j) {
             unsigned f = fl[j];
             // keep the flag tests inside the loop: hoisted, their 54 lane masks spill out of the SGPR file and
             // come back as two v_readlane per test, more than the two bit operations that make a weight here
             asm volatile("" : "+v"(f));
             const int sj = j & 1;
-            if (j + 1 < RES_SLOTS) RES_LOAD_A(j + 1)
+            if (j + 1 < NS) RES_LOAD_A(j + 1)
             __builtin_amdgcn_sched_barrier(0);
             {
                 // Branch free: every lane evaluates all four edges (LDS reads stay inside the halo'd tile, whose
@@ -620,7 +637,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 RES_EDGE(0, 0,     -si,  ci,   -sn,  cn,    si, -ci)      // s=( 1, 0): q=( si,-ci) h=( sn,-cn)
                 RES_EDGE(1, 1,      si, -ci,    sn, -cn,   -si,  ci)      // s=(-1, 0): q=(-si, ci) h=(-sn, cn)
                 __builtin_amdgcn_sched_barrier(0);
-                if (j + 1 < RES_SLOTS) RES_LOAD_B(j + 1)
+                if (j + 1 < NS) RES_LOAD_B(j + 1)
                 __builtin_amdgcn_sched_barrier(0);
                 RES_EDGE(2, 2,     -ci, -si,   -cn, -sn,    ci,  si)      // s=( 0, 1): q=( ci, si) h=( cn, sn)
                 RES_EDGE(3, 3,      ci,  si,    cn,  sn,   -ci, -si)      // s=( 0,-1): q=(-ci,-si) h=(-cn,-sn)
@@ -653,8 +670,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         auto phase_b = [&](auto fast_c) {
             constexpr bool FAST = decltype(fast_c)::value;
 #pragma unroll
-            for (int j = 0; j < RES_SLOTS; ++j) {
-                unsigned f = fl[j];
+            for (int j = 0; j < NS; ++j) {
+                    unsigned f = fl[j];
                 asm volatile("" : "+v"(f));
                 const float mo = mo_[j], ma = ma_[j];
                 rx[j] = fmaf(-alpha, apx[j], rx[j]);
@@ -683,8 +700,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             }
             RES_LOADP(0, Dp, Da)
 #pragma unroll
-            for (int j = 0; j < RES_SLOTS; ++j) {
-                if (j + 1 < RES_SLOTS) RES_LOADP(j + 1, Dp, Da)
+            for (int j = 0; j < NS; ++j) {
+                    if (j + 1 < NS) RES_LOADP(j + 1, Dp, Da)
                 __builtin_amdgcn_sched_barrier(0);
                 dx_[j] = fmaf(alpha, Dp[j & 1].x, dx_[j]);
                 dy_[j] = fmaf(alpha, Dp[j & 1].y, dy_[j]);
@@ -725,8 +742,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             float Ua[2];
             RES_LOADP(0, Up, Ua)
 #pragma unroll
-            for (int j = 0; j < RES_SLOTS; ++j) {
-                if (j + 1 < RES_SLOTS) RES_LOADP(j + 1, Up, Ua)
+            for (int j = 0; j < NS; ++j) {
+                    if (j + 1 < NS) RES_LOADP(j + 1, Up, Ua)
                 __builtin_amdgcn_sched_barrier(0);
                 char* T_ = (char*)lds + j * (LTILE * 4);
                 const float mo = mo_[j], ma = ma_[j];
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     int lo = loff;
     asm volatile("" : "+v"(lo));       // (else the nine store addresses are formed before the loop and spilled)
 #pragma unroll
-    for (int j = 0; j < RES_SLOTS; ++j) {
+    for (int j = 0; j < NS; ++j) {
         const unsigned f = fl[j];
         if (f & F_ACT) {
             const int i = ibase[j] + lo;

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/arap_opt.h"
@@ -90,6 +91,7 @@ struct Opt_State {
     // then it is tried again; every further timeout doubles the pause (8, 16, ... 1024), a checked success resets it.
     int res_cooldown = 0, res_backoff = 8;
     int tile = -1;              // ArapFlow_SetTile: phase-A variant of the two-kernel path; -1 = choose per solve
+    bool force_b8 = false;      // ARAPOPT_B8=1 (counter calibration): the 8-byte-per-lane form of phase B
 };
 
 struct Opt_Problem {
@@ -132,11 +134,14 @@ struct Opt_Plan {
     std::vector<int> h_ntiles;
     std::vector<std::vector<int>> h_tiles;   // what rd.tilelist holds per slot (skip the upload when nothing changed)
     std::vector<uint8_t> h_tiles_valid;
-    std::vector<std::vector<int>> h_tilepos;
+    std::vector<std::vector<int>> h_tilepos, h_bandx0;
+    uint8_t* d_resact = nullptr;    // [rtX * rtY] drop-in analysis: 32x8 tiles (fixed grid) that hold an active vertex
+    int res_tiles_all = 0;          // 32x8 tiles of the whole grid (share of active tiles: plan_active_tiles_majority)
     bool hole_pending = false;      // test hook ARAPOPT_FORCE_RES_FAIL=2: the next table upload leaves one workgroup out
     ResWg* d_wgmap = nullptr;       // [batch][RES_WGS]: one table per resident launch of a GN step
     std::vector<ResWg> h_wgmap;     // what d_wgmap holds
     int res_sets = 0;               // resident launches per GN step
+    std::vector<int> res_ns;        // per launch: tile slots in use = most tiles any of its workgroups holds
     int res_inflight = 0;           // solves of the fullest launch (diagnostic)
     unsigned res_launches = 0;
     // drop-in (Opt_*) plans: result of the Init-time analysis (k_analyse) of the caller's Mask / UrShape
@@ -194,7 +199,25 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     p->h_tiles.assign(batch, std::vector<int>());
     p->h_tiles_valid.assign(batch, 0);
     p->h_tilepos.assign(batch, std::vector<int>());
+    p->h_bandx0.assign(batch, std::vector<int>());
     return p;
+}
+
+// The resident kernel is instantiated per number of tile slots its loops run over (arap_resident.h): a launch takes
+// the instantiation for the most tiles any of its workgroups holds.
+typedef void (*ResidentKernel)(PlanDev, ResDev, int);
+template <bool STAMPS, int... NS>
+static const void* resident_kernel_of(int ns, std::integer_sequence<int, NS...>)
+{
+    static const ResidentKernel table[] = {k_pcg_resident<STAMPS, NS + 1>...};
+    return (const void*)table[ns - 1];
+}
+static const void* resident_kernel(bool stamps, int ns)
+{
+    if (ns < 1) ns = 1;
+    if (ns > RES_SLOTS) ns = RES_SLOTS;
+    return stamps ? resident_kernel_of<true>(ns, std::make_integer_sequence<int, RES_SLOTS>())
+                  : resident_kernel_of<false>(ns, std::make_integer_sequence<int, RES_SLOTS>());
 }
 
 // resident-path resources: active-tile lists, granules, error word
@@ -206,28 +229,36 @@ static void plan_enable_resident(Opt_Plan* p)
     hipDeviceProp_t prop;
     HC(hipGetDeviceProperties(&prop, st->device));
     if (prop.multiProcessorCount * 2 < RES_WGS) return;        // two resident workgroups per CU
-    if (hipFuncSetAttribute((const void*)k_pcg_resident<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            RES_LDS_BYTES) != hipSuccess) { (void)hipGetLastError(); return; }
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_pcg_resident<false>, RES_THREADS,
-                                                     RES_LDS_BYTES) != hipSuccess || occ < 2) {
-        (void)hipGetLastError();
-        return;
+    for (int ns = 1; ns <= RES_SLOTS; ++ns) {
+        if (hipFuncSetAttribute(resident_kernel(false, ns), hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_BYTES) !=
+            hipSuccess) { (void)hipGetLastError(); return; }
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, resident_kernel(false, ns), RES_THREADS, RES_LDS_BYTES) !=
+                hipSuccess || occ < 2) {
+            (void)hipGetLastError();
+            return;
+        }
     }
     const size_t sz_tl = align_up((size_t)p->batch * RES_MAX_TILES * sizeof(int), 256);
     const size_t sz_nt = align_up((size_t)p->batch * sizeof(int), 256);
     const size_t sz_gr = align_up((size_t)p->batch * RES_GRAN_PER_LAUNCH * 8, 256);   // one block per launch of a step
     const size_t sz_map = align_up((size_t)p->batch * RES_WGS * sizeof(ResWg), 256);
-    const size_t sz_tp = align_up((size_t)p->batch * p->pd.tilesX * p->pd.tilesY * sizeof(int), 256);
-    HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp));
-    HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp, st->stream));
+    p->rd.rtX = (p->W + RT_X - 1) / RT_X;
+    p->rd.rtY = (p->H + RT_Y - 1) / RT_Y;
+    const size_t sz_tp = align_up((size_t)p->batch * p->rd.rtX * p->rd.rtY * sizeof(int), 256);
+    const size_t sz_bx = align_up((size_t)p->batch * p->rd.rtY * sizeof(int), 256);
+    const size_t sz_ra = align_up((size_t)p->rd.rtX * p->rd.rtY, 256);               // drop-in analysis: tile activity
+    HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp + sz_bx + sz_ra));
+    HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp + sz_bx + sz_ra, st->stream));
     char* c = (char*)p->res_block;
     p->rd.gran = (unsigned long long*)c; c += sz_gr;
     p->rd.tilelist = (const int*)c; c += sz_tl;
     p->rd.ntiles = (const int*)c; c += sz_nt;
     p->rd.err = (unsigned*)c; c += 256;
     p->d_wgmap = (ResWg*)c; c += sz_map;
-    p->rd.tilepos = (const int*)c;
+    p->rd.tilepos = (const int*)c; c += sz_tp;
+    p->rd.bandx0 = (const int*)c; c += sz_bx;
+    p->d_resact = (uint8_t*)c;
     p->pd.res_err = p->rd.err;
     p->rd.stamps = nullptr;
     {
@@ -247,34 +278,79 @@ static void plan_enable_resident(Opt_Plan* p)
     }
     const char* sd = getenv("ARAPOPT_STAMPS");      // diagnostic build of the resident kernel (tools/res_stamps.py)
     if (sd && sd[0] == '1') {
-        HC(hipFuncSetAttribute((const void*)k_pcg_resident<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               RES_LDS_BYTES));
+        for (int ns = 1; ns <= RES_SLOTS; ++ns)
+            HC(hipFuncSetAttribute(resident_kernel(true, ns), hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_BYTES));
         HC(hipMalloc(&p->rd.stamps, RES_WGS * 8 * sizeof(unsigned long long)));
         HC(hipMemset(p->rd.stamps, 0, RES_WGS * 8 * sizeof(unsigned long long)));
     }
     p->res_capable = true;
 }
 
-// active-tile list of one slot (ascending tile indices), its length and the inverse map tile -> position.
+// The resident kernel's work list of one solve (arap_resident.h): 32 x 8 tiles in bands of 8 rows; within a band the
+// tiles start at `bandx0` (the band's first active x when `aligned`, else 0) and follow each other every 32 columns;
+// tiles without an active vertex are left out.  `tiles` receives the origins (x0 + W y0) band by band.
+static void build_resident_tiles(const uint8_t* mask_red, int W, int H, bool aligned, std::vector<int>& tiles,
+                                 std::vector<int>& bandx0, uint64_t* nactive)
+{
+    const int rtY = (H + RT_Y - 1) / RT_Y;
+    tiles.clear();
+    bandx0.assign(rtY, 0);
+    std::vector<uint8_t> col(W);
+    uint64_t na = 0;
+    for (int band = 0; band < rtY; ++band) {
+        std::fill(col.begin(), col.end(), 0);
+        const int y0 = band * RT_Y, y1 = std::min(H, y0 + RT_Y);
+        for (int y = y0; y < y1; ++y) {
+            const uint8_t* row = mask_red + (size_t)W * y;
+            for (int x = 0; x < W; ++x) {
+                const uint8_t a = row[x] == 0;
+                col[x] |= a;
+                na += a;
+            }
+        }
+        int xmin = 0, xmax = -1;
+        for (int x = 0; x < W; ++x)
+            if (col[x]) { if (xmax < 0) xmin = x; xmax = x; }
+        if (xmax < 0) continue;
+        const int xs = aligned ? xmin : 0;
+        bandx0[band] = xs;
+        for (int x0 = xs; x0 <= xmax; x0 += RT_X) {
+            bool any = false;
+            for (int x = x0; x < W && x < x0 + RT_X && !any; ++x) any = col[x] != 0;
+            if (any) tiles.push_back(x0 + W * y0);
+        }
+    }
+    if (nactive) *nactive = na;
+}
+
+// Upload one slot's work list: origins, their count, the bands' first x and the inverse map (band, column) -> position.
 // Enqueued on `cs` (the caller orders it before the kernels that read the lists and after those that still use the
 // old ones).  The sources are plan-owned host vectors that live until the next upload of the slot.
-static void plan_upload_tiles(Opt_Plan* p, int slot, const std::vector<int>& tiles, hipStream_t cs)
+static void plan_upload_tiles(Opt_Plan* p, int slot, const std::vector<int>& tiles, const std::vector<int>& bandx0,
+                              hipStream_t cs)
 {
     const int nt = (int)tiles.size();
-    const int nt_all = p->pd.tilesX * p->pd.tilesY;
     p->h_ntiles[slot] = nt;
     if (!p->res_capable) return;
-    if (p->h_tiles_valid[slot] && p->h_tiles[slot] == tiles) return;      // the device already holds this list
+    if (p->h_tiles_valid[slot] && p->h_tiles[slot] == tiles && p->h_bandx0[slot] == bandx0) return;   // already there
     p->h_tiles[slot] = tiles;
+    p->h_bandx0[slot] = bandx0;
     p->h_tiles_valid[slot] = 1;
+    const int rtX = p->rd.rtX, rtY = p->rd.rtY;
     if (nt <= RES_MAX_TILES) {
         std::vector<int>& pos = p->h_tilepos[slot];
-        pos.assign(nt_all, -1);
-        for (int i = 0; i < nt; ++i) pos[tiles[i]] = i;
+        pos.assign((size_t)rtX * rtY, -1);
+        for (int i = 0; i < nt; ++i) {
+            const int y0 = tiles[i] / p->W, x0 = tiles[i] - y0 * p->W;
+            const int band = y0 / RT_Y, k = (x0 - bandx0[band]) / RT_X;
+            pos[(size_t)band * rtX + k] = i;
+        }
         if (nt > 0)
             HC(hipMemcpyAsync((void*)(p->rd.tilelist + (size_t)slot * RES_MAX_TILES), p->h_tiles[slot].data(),
                               sizeof(int) * nt, hipMemcpyHostToDevice, cs));
-        HC(hipMemcpyAsync((void*)(p->rd.tilepos + (size_t)slot * nt_all), pos.data(), sizeof(int) * nt_all,
+        HC(hipMemcpyAsync((void*)(p->rd.tilepos + (size_t)slot * rtX * rtY), pos.data(), sizeof(int) * pos.size(),
+                          hipMemcpyHostToDevice, cs));
+        HC(hipMemcpyAsync((void*)(p->rd.bandx0 + (size_t)slot * rtY), p->h_bandx0[slot].data(), sizeof(int) * rtY,
                           hipMemcpyHostToDevice, cs));
     }
     HC(hipMemcpyAsync((void*)(p->rd.ntiles + slot), &p->h_ntiles[slot], sizeof(int), hipMemcpyHostToDevice, cs));
@@ -290,22 +366,27 @@ static void plan_analyse_for_resident(Opt_Plan* p)
     p->opt_res_ok = false;
     if (p->res_frames) return;
     Opt_State* st = p->st;
-    if (!p->d_notgrid) HC(hipMalloc(&p->d_notgrid, sizeof(int)));
+    // without the resident resources there is still one use of the result: the share of active tiles steers the
+    // automatic phase-A variant of the two-kernel path
+    const int rtX = (p->W + RT_X - 1) / RT_X, rtY = (p->H + RT_Y - 1) / RT_Y;
+    const int nt_all = rtX * rtY;
+    if (!p->d_notgrid) HC(hipMalloc(&p->d_notgrid, sizeof(int) + (size_t)nt_all));
+    uint8_t* d_act = p->d_resact ? p->d_resact : (uint8_t*)(p->d_notgrid + 1);
     HC(hipMemsetAsync(p->d_notgrid, 0, sizeof(int), st->stream));
-    hipLaunchKernelGGL(k_analyse, p->grid(), p->blk(), 0, st->stream, p->pd, p->d_notgrid);
-    const int nt_all = p->pd.tilesX * p->pd.tilesY;
+    hipLaunchKernelGGL(k_analyse, dim3(rtX, rtY, 1), dim3(RT_X, RT_Y, 1), 0, st->stream, p->pd, d_act, p->d_notgrid);
     std::vector<uint8_t> act(nt_all);
     int notgrid = 1;
-    HC(hipMemcpyAsync(act.data(), p->pd.tileact, nt_all, hipMemcpyDeviceToHost, st->stream));
+    HC(hipMemcpyAsync(act.data(), d_act, nt_all, hipMemcpyDeviceToHost, st->stream));
     HC(hipMemcpyAsync(&notgrid, p->d_notgrid, sizeof(int), hipMemcpyDeviceToHost, st->stream));
     HC(hipStreamSynchronize(st->stream));
-    std::vector<int> tiles;
+    std::vector<int> tiles, bandx0(rtY, 0);                     // fixed grid: every band starts at x = 0
     for (int t = 0; t < nt_all; ++t)
-        if (act[t]) tiles.push_back(t);
+        if (act[t]) tiles.push_back((t % rtX) * RT_X + p->W * ((t / rtX) * RT_Y));
     const int nt = (int)tiles.size();
-    p->h_ntiles[0] = nt;                        // also steers the automatic phase-A variant of the two-kernel path
+    p->h_ntiles[0] = nt;
+    p->res_tiles_all = nt_all;
     if (notgrid || !p->res_capable || !st->use_resident || st->res_cooldown > 0 || nt > RES_MAX_TILES) return;
-    plan_upload_tiles(p, 0, tiles, st->stream);
+    plan_upload_tiles(p, 0, tiles, bandx0, st->stream);
     p->opt_res_ok = true;
     p->opt_res_slot = p->hslots[0];
 }
@@ -465,10 +546,18 @@ static bool plan_resident_pack(Opt_Plan* p)
 {
     std::vector<ResWg> map;
     const int nsets = resident_deal(p->h_ntiles.data(), p->nb, &map, &p->res_inflight);
-    const bool same = nsets == p->res_sets && map.size() == p->h_wgmap.size() &&
+    std::vector<int> ns(nsets, 1);
+    for (size_t i = 0; i < map.size(); ++i)
+        if (map[i].slot >= 0) {
+            const int t = (p->h_ntiles[map[i].slot] + map[i].wgs - 1) / map[i].wgs;      // tiles of the group's fullest workgroup
+            int& m = ns[i / RES_WGS];
+            m = t > m ? t : m;
+        }
+    const bool same = nsets == p->res_sets && ns == p->res_ns && map.size() == p->h_wgmap.size() &&
                       memcmp(map.data(), p->h_wgmap.data(), map.size() * sizeof(ResWg)) == 0;
     if (same) return false;
     p->h_wgmap.swap(map);
+    p->res_ns.swap(ns);
     p->res_sets = nsets;
     return true;
 }
@@ -595,7 +684,8 @@ static bool plan_active_tiles_majority(const Opt_Plan* p)
 {
     long act = 0;
     for (int b = 0; b < p->nb; ++b) act += p->h_ntiles[b];
-    return 2 * act >= (long)p->nb * p->pd.tilesX * p->pd.tilesY;
+    const long all = (long)((p->W + RT_X - 1) / RT_X) * ((p->H + RT_Y - 1) / RT_Y);
+    return 2 * act >= (long)p->nb * all;
 }
 
 // phase A of the two-kernel path: direct-load kernel or an LDS-staged tile shape (ArapFlow_SetTile)
@@ -649,16 +739,16 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
         for (int set = 0; set < p->res_sets; ++set) {
             rd.wgmap = p->d_wgmap + (size_t)set * RES_WGS;
             rd.gran = p->rd.gran + gran_per_launch * set;
+            const ResidentKernel kern = (ResidentKernel)resident_kernel(rd.stamps != nullptr, p->res_ns[set]);
             if (rd.stamps)
-                hipLaunchKernelGGL(k_pcg_resident<true>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
+                hipLaunchKernelGGL(kern, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, s, p->pd, rd, L);
             else
-                LAUNCH_DYN(p, s, "PCGResident", k_pcg_resident<false>, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES,
-                           p->pd, rd, L);
+                LAUNCH_DYN(p, s, "PCGResident", kern, dim3(RES_WGS), dim3(RES_THREADS), RES_LDS_BYTES, p->pd, rd, L);
         }
     } else {
         for (int l = 0; l < L; ++l) {
             launch_pcg_a(p, s, l);
-            if ((p->N & 3) == 0 && !p->pd.lm)      // 16-byte accesses need every frame's images 16-byte aligned
+            if ((p->N & 3) == 0 && !p->pd.lm && !p->st->force_b8)      // 16-byte accesses need every frame's images 16-byte aligned
                 LAUNCH(p, s, "PCGStepB", k_pcg_b4, dim3((p->N / 4 + 255) / 256, p->nb, 1), dim3(256), p->pd, l);
             else
                 LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
@@ -988,6 +1078,13 @@ Opt_State* Opt_NewState(Opt_InitializationParameters params)
     HC(hipEventCreate(&st->t1));
     const char* ng = getenv("ARAPOPT_NO_GRAPH");
     st->use_graph = !(ng && ng[0] == '1');
+    if (const char* tv = getenv("ARAPOPT_TILE")) {                     // experiments: phase-A variant, "TXxTY" or "0x0"
+        int tx = -1, ty = -1;
+        if (sscanf(tv, "%dx%d", &tx, &ty) == 2)
+            for (int v = 0; v < 6; ++v)
+                if (kTileShapes[v][0] == tx && kTileShapes[v][1] == ty) st->tile = v;
+    }
+    if (const char* b8 = getenv("ARAPOPT_B8")) st->force_b8 = b8[0] == '1';   // experiments: 8-byte form of phase B
     return st;
 }
 
@@ -1462,30 +1559,12 @@ int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rg
     }
     memcpy(smask, mask_red, N);
     if (rgb) memcpy(srgb, rgb, 3 * N);
-    // active vertices and active 64x4 tiles of this frame, row-major (resident path work list)
+    // active vertices and the resident kernel's work list of this frame (aligned 32x8 tiles, band by band)
+    std::vector<int> tiles, bandx0;
     uint64_t na = 0;
-    std::vector<int> tiles;
-    {
-        const int tX = s->plan->pd.tilesX, tY = s->plan->pd.tilesY;
-        std::vector<uint8_t> colact(tX);
-        for (int ty = 0; ty < tY; ++ty) {
-            std::fill(colact.begin(), colact.end(), 0);
-            for (int y = ty * TILE_Y; y < H && y < (ty + 1) * TILE_Y; ++y) {
-                const uint8_t* row = mask_red + (size_t)W * y;
-                for (int tx = 0; tx < tX; ++tx) {
-                    const int x1 = std::min(W, (tx + 1) * TILE_X);
-                    unsigned cnt = 0;
-                    for (int x = tx * TILE_X; x < x1; ++x) cnt += row[x] == 0;
-                    na += cnt;
-                    colact[tx] |= cnt != 0;
-                }
-            }
-            for (int tx = 0; tx < tX; ++tx)
-                if (colact[tx]) tiles.push_back(ty * tX + tx);
-        }
-    }
+    build_resident_tiles(mask_red, W, H, true, tiles, bandx0, &na);
     s->nactive[slot] = na;
-    plan_upload_tiles(s->plan, (int)slot, tiles, s->copy);
+    plan_upload_tiles(s->plan, (int)slot, tiles, bandx0, s->copy);
     const FrameDev& f = s->hfr[slot];
     HC(hipMemcpyAsync(f.T, T, N * sizeof(float2), hipMemcpyHostToDevice, s->copy));
     HC(hipMemcpyAsync(f.mask, smask, N, hipMemcpyHostToDevice, s->copy));

@@ -53,3 +53,31 @@ def load_cat512(golden_dir):
     wrgb = np.array(Image.open(os.path.join(d, "cat512_wRGB.png")).convert("RGB"))
     wmsk = np.array(Image.open(os.path.join(d, "cat512_wMsk.png")).convert("L"))
     return dict(rgb=rgb, mask_red=mred, constraints=cons, golden_flow=gflow, golden_wrgb=wrgb, golden_wmsk=wmsk)
+
+
+def t4_bands(golden_dir):
+    """Tier T4 acceptance bands from the committed calibration table tests/golden/t4_variants.json (made by
+    tests/golden/make_t4_variants.py): eight arithmetic variants of the CPU oracle (f32 / f64, sequential / float64
+    sums, libm / spec trig, fused multiply-adds on / off) and six runs of the product's arithmetic from an initial
+    Angle perturbed by N(0, 1e-6 rad), all on the reference's cat512 fixture, full 19/8/400 schedule.  Every one of
+    them is a correct evaluation of the reference's algorithm; the bands are what THEY span (the product's own row is
+    left out, so the band is not drawn around the value under test):
+      cost      : mean +- 3 standard deviations of the other trajectories' final costs (they scatter over 55.8 .. 61.1
+                  with a standard deviation of ~2: the final cost of this unconverged schedule is itself a random
+                  variable of the rounding trajectory; a 1e-6 rad perturbation of the start moves it by 6 %)
+      rel_l2    : 1.1 x the largest rel-L2 to the reference golden among the other trajectories
+      median_px : 1.1 x their largest median error
+      handle_px : 2e-4 px, SURVEY 8c's bound (the product measures 1.8e-4; two other correct trajectories of the table
+                  sit at 2.1e-4 and 7.6e-4, so this bound is the tightest the algorithm's own scatter allows)"""
+    import json
+    import os
+    tab = json.load(open(os.path.join(golden_dir, "t4_variants.json")))
+    others = [v for k, v in tab["variants"].items() if k != tab["product_variant"]]
+    others += list(tab.get("perturbed_starts_product_arithmetic", {}).values())
+    costs = [v["final_cost"] for v in others]
+    import numpy as _np
+    mu, sd = float(_np.mean(costs)), float(_np.std(costs, ddof=1))
+    return dict(cost=(mu - 3.0 * sd, mu + 3.0 * sd),
+                rel_l2=1.1 * max(v["rel_l2_vs_golden"] for v in others),
+                median_px=1.1 * max(v["median_px_vs_golden"] for v in others),
+                handle_px=2e-4, quads=5, table=tab)

@@ -153,13 +153,16 @@ def test_T4_full_schedule_cat512_vs_reference_golden(gpu_state, golden_dir):
     fs.close()
     flow, gold = r["flow"], cat["golden_flow"]
     act = cat["mask_red"] == 0
+    band = helpers.t4_bands(golden_dir)        # from the committed table of oracle variants, not from this result
     assert np.all(flow[~act] == 0)
     for x1, y1, x2, y2 in cat["constraints"]:
-        assert np.abs(flow[y1, x1] - gold[y1, x1]).max() < 2e-3
-    assert helpers.rel_l2(flow[act], gold[act]) < 1.2e-2
-    assert np.median(np.linalg.norm(flow - gold, axis=-1)[act]) < 0.1
-    assert abs(helpers.neg_det_quads(flow, act) - helpers.neg_det_quads(gold, act)) <= 5
-    assert 50.0 < r["cost"] < 65.0
+        assert np.abs(flow[y1, x1] - gold[y1, x1]).max() < band["handle_px"]
+    assert helpers.rel_l2(flow[act], gold[act]) < band["rel_l2"]
+    assert np.median(np.linalg.norm(flow - gold, axis=-1)[act]) < band["median_px"]
+    assert abs(helpers.neg_det_quads(flow, act) - helpers.neg_det_quads(gold, act)) <= band["quads"]
+    assert band["cost"][0] < r["cost"] < band["cost"][1]
+    # and it IS the table's product row: the HIP path is the bit-level twin of that oracle variant (tier T3)
+    assert r["cost"] == band["table"]["variants"][band["table"]["product_variant"]]["final_cost"]
     # the warped outputs of that solve vs the reference's committed PNGs: the fields differ by the
     # rounding-trajectory noise above, so compare coverage, not pixels
     assert (r["warped_mask"] != cat["golden_wmsk"]).mean() < 0.01

@@ -85,23 +85,28 @@ def test_committed_goldens_reproduced(oracle, golden_dir, name):
 
 
 def test_T4_full_schedule_vs_reference_golden(oracle, golden_dir):
-    """The reference's only solver known answer: ARAP/warping/cat512_iFlo.flo (schedule 19/8/400).
-    Tolerances are the calibrated self-variability of SURVEY 8c: the schedule runs float32 PCG far
-    past stability, so two correct float32 implementations differ by ~4e-3..9e-3 rel-L2."""
+    """The reference's only solver known answer: ARAP/warping/cat512_iFlo.flo (schedule 19/8/400).  The schedule runs
+    float32 PCG far past stability and far short of convergence, so two correct implementations differ by 3.5e-3 ..
+    1e-2 rel-L2 and 15 % in final cost; the acceptance bands come from the committed table of the oracle's own
+    arithmetic variants and perturbed starts (helpers.t4_bands), not from the value under test."""
     cat = helpers.load_cat512(golden_dir)
+    band = helpers.t4_bands(golden_dir)
     O, A, costs = oracle.frame(cat["mask_red"], cat["constraints"], dtype=np.float32, mode=1, trig=1)
     flow = oracle.flow_from_offset(O)
     gold = cat["golden_flow"]
     act = cat["mask_red"] == 0
     assert np.all(flow[~act] == 0) and np.all(gold[~act] == 0)          # off-mask flow exactly 0
     for x1, y1, x2, y2 in cat["constraints"]:                            # handles
-        assert np.abs(flow[y1, x1] - gold[y1, x1]).max() < 2e-3
+        assert np.abs(flow[y1, x1] - gold[y1, x1]).max() < band["handle_px"]
         assert np.abs(flow[y1, x1] - np.array([x2 - x1, y2 - y1])).max() < 5e-3
-    assert helpers.rel_l2(flow[act], gold[act]) < 1.2e-2
+    assert helpers.rel_l2(flow[act], gold[act]) < band["rel_l2"]
     err = np.linalg.norm(flow - gold, axis=-1)[act]
-    assert np.median(err) < 0.1
-    assert abs(helpers.neg_det_quads(flow, act) - helpers.neg_det_quads(gold, act)) <= 5
-    assert 50.0 < costs[-1] < 65.0                                       # SURVEY 8c: 55.8 .. 58.1
+    assert np.median(err) < band["median_px"]
+    assert abs(helpers.neg_det_quads(flow, act) - helpers.neg_det_quads(gold, act)) <= band["quads"]
+    assert band["cost"][0] < costs[-1] < band["cost"][1]
+    # the committed table's row of this very variant is what the oracle still computes
+    row = band["table"]["variants"][band["table"]["product_variant"]]
+    assert costs[-1] == row["final_cost"] and abs(helpers.rel_l2(flow[act], gold[act]) - row["rel_l2_vs_golden"]) < 1e-12
 
 
 def test_warp_oracle_vs_reference_cat512(oracle, golden_dir):

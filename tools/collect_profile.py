@@ -4,12 +4,13 @@
 
 NAME is one of CONFIGS below (the BASELINE.json configs that fit one GPU, plus the roofline configuration mask == 0).
 For the configuration it runs, each as its own process with the program directly after `--` (no env/sh hop):
-  1. python3 bench.py <args>                                   -> profiles/<round>_<NAME>_bench.json   (the JSON line)
-  2. rocprofv3 --kernel-trace --stats -- python3 bench.py ...   -> profiles/<round>_<NAME>_kernel_stats.csv
+  1. python3 bench.py <args>                                   -> <round>_<NAME>_bench.json   (the JSON line)
+  2. rocprofv3 --kernel-trace --stats -- python3 bench.py ...   -> <round>_<NAME>_kernel_stats.csv
   3. rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md "HBM"), and two SQ passes
      on a short schedule (1 ramp step x 2 GN steps x 400 PCG iterations)
   4. the instrumented build of the resident kernel (ARAPOPT_STAMPS=1): share of an iteration spent in the two group waits
-and condenses 2-4 into profiles/<round>_<NAME>_counters.json, which bench.py reads back for `roofline.traffic`,
+and condenses 2-4 into <round>_<NAME>_counters.json (all three under gpurun_out/profiles/, the directory that travels
+back from the GPU box; copied into profiles/ by hand), which bench.py reads back from profiles/ for `roofline.traffic`,
 `hbm_frac_by_counters`, `valu_issue_frac`, `wait_frac` -- keyed by the configuration's signature and the hash of the
 kernel sources, so a record made for other code or another workload is never quoted.
 """
@@ -86,7 +87,9 @@ def main():
     os.environ["TMPDIR"] = "/tmp"
     from tools import profile_key
     args = CONFIGS[a.name] + a.extra
-    prof = os.path.join(ROOT, "profiles")
+    # written under gpurun_out/ (the only directory that travels back from the GPU box); copy into profiles/ afterwards
+    prof = os.path.join(ROOT, "gpurun_out", "profiles")
+    os.makedirs(prof, exist_ok=True)
     outdir = os.path.join(ROOT, "gpurun_out", "cp_" + a.name)
     os.makedirs(outdir, exist_ok=True)
     pre = os.path.join(prof, "%s_%s" % (a.round, a.name))
