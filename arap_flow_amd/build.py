@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "arapopt.hip")
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("arapopt.hip", "arap_device.h", "arap_kernels.h", "arap_warp.h", "arap_resident.h", "arap_lm.h", "arap_tiled.h")]
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("arapopt.hip", "arap_device.h", "arap_kernels.h", "arap_warp.h", "arap_resident.h", "arap_lm.h", "arap_tiled.h", "arap_stream.h")]
 DEPS.append(os.path.join(HERE, "..", "include", "arap_opt.h"))
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libarapopt.so")

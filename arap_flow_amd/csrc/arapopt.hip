@@ -27,6 +27,7 @@
 #include "arap_resident.h"
 #include "arap_lm.h"
 #include "arap_tiled.h"
+#include "arap_stream.h"
 #include "arap_warp.h"
 
 using namespace arap;
@@ -92,6 +93,7 @@ struct Opt_State {
     int res_cooldown = 0, res_backoff = 8;
     int tile = -1;              // ArapFlow_SetTile: phase-A variant of the two-kernel path; -1 = choose per solve
     bool force_b8 = false;      // ARAPOPT_B8=1 (counter calibration): the 8-byte-per-lane form of phase B
+    int stream_a = 0;           // ARAPOPT_STREAM_A=1 (experiments): the tiled k_pcg_a_grid instead of the marching kernel
 };
 
 struct Opt_Problem {
@@ -126,6 +128,8 @@ struct Opt_Plan {
     // resident PCG (arap_resident.h): only for the frame solver (pixel-grid UrShape, host-known masks)
     bool res_capable = false;       // device has 256 CUs and the kernel fits one workgroup per CU
     bool res_frames = false;        // plan is driven by ArapFlow_Solver
+    bool grid_u = false;            // UrShape is the pixel grid on every active vertex (frame solver: always; drop-in:
+                                    // what the last analysis found): the streaming phase A without UrShape loads applies
     // ArapFlow_Solver reports one cost, the one after the last step of the last ramp iteration: the costs the
     // reference evaluates at Init and after every step (for its log) are skipped unless cost_wanted
     bool lazy_cost = false, cost_wanted = true;
@@ -385,6 +389,7 @@ static void plan_analyse_for_resident(Opt_Plan* p)
     const int nt = (int)tiles.size();
     p->h_ntiles[0] = nt;
     p->res_tiles_all = nt_all;
+    p->grid_u = notgrid == 0;
     if (notgrid || !p->res_capable || !st->use_resident || st->res_cooldown > 0 || nt > RES_MAX_TILES) return;
     plan_upload_tiles(p, 0, tiles, bandx0, st->stream);
     p->opt_res_ok = true;
@@ -694,8 +699,23 @@ static const int kTileShapes[6][2] = {{0, 0}, {16, 16}, {32, 8}, {64, 4}, {32, 1
 static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
 {
     int v = p->st->tile;
+    if (v < 0 && p->grid_u && !p->pd.lm) {
+        // default for the pixel-grid UrShape (every frame-solver plan): the marching kernel of arap_stream.h -- no
+        // UrShape loads, every vertex fetched once, XCD-aware strip order; 1-D launch of frames x 8 x ceil(tiles / 8)
+        constexpr int RB = 5;                                  // 20 rows per workgroup
+        const int sX = p->pd.tilesX, cY = (p->H + 4 * RB - 1) / (4 * RB), chunk = (sX * cY + 7) / 8;
+        if (p->st->stream_a == 1) {
+            constexpr int TX = 64, TY = 8;
+            const int tX = (p->W + TX - 1) / TX, tY = (p->H + TY - 1) / TY, ch = (tX * tY + 7) / 8;
+            LAUNCH(p, s, "PCGStepA", (k_pcg_a_grid<TX, TY>), dim3((unsigned)(p->nb * 8 * ch)), dim3(TX, TY, 1), p->pd, l, tX,
+                   tY, ch);
+        } else {
+            LAUNCH(p, s, "PCGStepA", (k_pcg_a_march<RB>), dim3((unsigned)(p->nb * 8 * chunk)), dim3(256), p->pd, l, sX, cY, chunk);
+        }
+        return;
+    }
     if (v < 0) {
-        // default: LDS-staged 64x8 tiles when most tiles are active (profiles/r01_tile_sweep_two_kernel_path.txt:
+        // generic UrShape: LDS-staged 64x8 tiles when most tiles are active (profiles/r01_tile_sweep_two_kernel_path.txt:
         // +14 % at full masks), direct loads for sparse masks (the staging of empty halo rows does not pay)
         v = plan_active_tiles_majority(p) ? 5 : 0;
     }
@@ -748,8 +768,11 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
     } else {
         for (int l = 0; l < L; ++l) {
             launch_pcg_a(p, s, l);
-            if ((p->N & 3) == 0 && !p->pd.lm && !p->st->force_b8)      // 16-byte accesses need every frame's images 16-byte aligned
-                LAUNCH(p, s, "PCGStepB", k_pcg_b4, dim3((p->N / 4 + 255) / 256, p->nb, 1), dim3(256), p->pd, l);
+            if ((p->N & 3) == 0 && !p->pd.lm && !p->st->force_b8) {     // 16-byte accesses need every frame's images 16-byte aligned
+                const dim3 gq((p->N / 4 + 255) / 256, p->nb, 1);
+                if (p->st->tile < 0) LAUNCH(p, s, "PCGStepB", k_pcg_b4_lean, gq, dim3(256), p->pd, l);
+                else LAUNCH(p, s, "PCGStepB", k_pcg_b4, gq, dim3(256), p->pd, l);        // (explicit variants: the sweep's baseline)
+            }
             else
                 LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
         }
@@ -784,7 +807,7 @@ static void plan_gn_step(Opt_Plan* p)
         return;
     }
     // the captured launches bake in the path (resident: number of launches; two-kernel: phase-A variant)
-    const int res_now = res ? p->res_sets : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p));
+    const int res_now = res ? p->res_sets : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p)) - 16 * (int)p->grid_u;
     if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
@@ -1085,6 +1108,7 @@ Opt_State* Opt_NewState(Opt_InitializationParameters params)
                 if (kTileShapes[v][0] == tx && kTileShapes[v][1] == ty) st->tile = v;
     }
     if (const char* b8 = getenv("ARAPOPT_B8")) st->force_b8 = b8[0] == '1';   // experiments: 8-byte form of phase B
+    if (const char* sa = getenv("ARAPOPT_STREAM_A")) st->stream_a = atoi(sa);
     return st;
 }
 
@@ -1473,6 +1497,7 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
     s->plan = plan_create(st, (int)W, (int)H, (int)batch);
     plan_enable_resident(s->plan);
     s->plan->res_frames = s->plan->res_capable;
+    s->plan->grid_u = true;                                   // k_frame_reset writes U = the pixel grid
     const size_t N = s->N;
     const size_t sz2 = align_up(N * sizeof(float2), 256), sz1 = align_up(N * sizeof(float), 256);
     const size_t szb = align_up(N, 256), sz3 = align_up(3 * N, 256), szk = align_up(N * 8, 256);

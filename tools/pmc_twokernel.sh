@@ -21,6 +21,16 @@ for (k, c), (n, v) in sorted(agg.items()):
     print("%-10s %-30s %-14s launches %4d  avg %14.1f" % (sys.argv[1], k, c, n, v / n))
 PY
 }
+run "auto_fetch" FETCH_SIZE
+run "auto_write" WRITE_SIZE
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmc2k_s0 -- python3 bench.py $ARGS $COMMON > gpurun_out/pmc2k_stats_auto.log 2>&1
+head -4 "$(find /tmp/pmc2k_s0 -name '*kernel_stats.csv' | head -1)"
+export ARAPOPT_STREAM_A=1
+run "grid_fetch" FETCH_SIZE
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmc2k_s1 -- python3 bench.py $ARGS $COMMON > gpurun_out/pmc2k_stats_grid.log 2>&1
+head -3 "$(find /tmp/pmc2k_s1 -name '*kernel_stats.csv' | head -1)"
+unset ARAPOPT_STREAM_A
+if [ -n "$PMC2K_SHORT" ]; then exit 0; fi
 for tile in 64x8 0x0; do
   export ARAPOPT_TILE=$tile
   run "A${tile}_fetch" FETCH_SIZE
