@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarapopt.so")
+LIB_PATH = os.environ.get("ARAPOPT_LIB") or os.path.join(_HERE, "lib", "libarapopt.so")     # (ARAPOPT_LIB: kernel experiments)
 
 
 class Opt_InitializationParameters(C.Structure):

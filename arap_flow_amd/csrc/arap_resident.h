@@ -56,13 +56,23 @@ constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / co
                               + ((RES_MAX_HALO * 8 + 15) / 16) * 16   // halo list (u16), then the decoded halo table (uint2)
                               + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (67.4 KB: 2 per CU)
 static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two workgroups per CU");
-#ifndef RES_PAIR_SLOTS
-#define RES_PAIR_SLOTS 1      // slots of phase A the scheduler may interleave (register pressure vs latency hiding)
+#ifndef RES_HALO_REG_SLOTS
+#define RES_HALO_REG_SLOTS 8  // keep the decoded halo entries in registers when at most this many tile slots are in use
+#endif
+#ifndef RES_OWN_LOCAL
+#define RES_OWN_LOCAL 1       // a group wait takes the workgroup's own partial from its register, not from its granules
+#endif
+#ifndef RES_POLL_SLEEP
+#define RES_POLL_SLEEP 1      // s_sleep between two sweeps of a group wait (0: poll back to back)
 #endif
 constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
 // granules of one launch (u64 entries): [2 parity][wgs][2] per group, packed back to back (4 per workgroup), then the
 // second-level granules of groups that span XCDs: [2 parity][8 XCD runs][16: one line each] for up to 4 such groups
-constexpr int RES_GRAN_L1 = 2 * RES_WGS * 2;
+#ifndef RES_GRAN_STRIDE
+#define RES_GRAN_STRIDE 2     // u64 between two workgroups' granule pairs: 2 = packed (8 pairs per 128-byte line), 16 = a line each
+#endif
+constexpr int RES_GS = RES_GRAN_STRIDE;
+constexpr int RES_GRAN_L1 = 2 * RES_WGS * RES_GS;
 constexpr int RES_GRAN2_STRIDE = 16;            // u64 per second-level granule pair: one 128-byte line per XCD run
 constexpr int RES_GRAN2_GROUP = 2 * 8 * RES_GRAN2_STRIDE;
 constexpr int RES_GRAN_PER_LAUNCH = RES_GRAN_L1 + 4 * RES_GRAN2_GROUP;
@@ -155,7 +165,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
     if (wave == 0) {
         // the whole group waits for the slowest publisher: this wave's few instructions go first on its SIMD
         __builtin_amdgcn_s_setprio(3);
-        unsigned long long* buf = gran_group + (size_t)(epoch & 1u) * wgs * 2;
+        unsigned long long* buf = gran_group + (size_t)(epoch & 1u) * wgs * RES_GS;
         // lane 0 holds the partial: v_readfirstlane (a __shfl would be two ds_bpermute round trips)
         part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
                                 __builtin_amdgcn_readfirstlane(__double2loint(part)));
@@ -164,9 +174,9 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
             const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
             const unsigned long long gv = ((unsigned long long)epoch << 32) | hw;
             if (fast)
-                __hip_atomic_store(buf + rank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(buf + rank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else
-                __hip_atomic_store(buf + rank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(buf + rank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         double v = 0.0;
         bool ok = false;
@@ -174,15 +184,18 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
             v = 0.0;
             bool mine_ok = true;
             for (int m = lane; m < wgs; m += 64) {
-                const unsigned long long lo = __hip_atomic_load(buf + 2 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long lo = __hip_atomic_load(buf + RES_GS * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long hi =
-                    __hip_atomic_load(buf + 2 * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mine_ok = mine_ok && (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
-                v += __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                    __hip_atomic_load(buf + RES_GS * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // this workgroup's own granules need not have travelled to L2 and back: its value is at hand (the
+                // last workgroup to arrive -- the critical path -- then finishes with its first sweep)
+                const bool own = RES_OWN_LOCAL && m == rank;
+                mine_ok = mine_ok && (own || ((unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch));
+                v += own ? part : __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
             }
             ok = __all(mine_ok) || nowait;
             if (ok) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (RES_POLL_SLEEP) __builtin_amdgcn_s_sleep(1);
         }
         v = wave_sum_l63(v);
         if (lane == 63) {
@@ -219,7 +232,7 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
         const int sub = rank >> 6, srank = rank & 63, nsub = wgs >> 6;
-        unsigned long long* buf = gran_group + (size_t)sub * 256 + (size_t)(epoch & 1u) * 128;
+        unsigned long long* buf = gran_group + (size_t)sub * (128 * RES_GS) + (size_t)(epoch & 1u) * (64 * RES_GS);
         part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
                                 __builtin_amdgcn_readfirstlane(__double2loint(part)));
         if (lane < 2) {
@@ -227,19 +240,20 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
             const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
             const unsigned long long gv = ((unsigned long long)epoch << 32) | hw;
             if (subfast)
-                __hip_atomic_store(buf + srank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(buf + srank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else
-                __hip_atomic_store(buf + srank * 2 + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(buf + srank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         double v = 0.0;
         bool ok = false;
         for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {           // level 1: lane k <-> workgroup k of the run
-            const unsigned long long lo = __hip_atomic_load(buf + 2 * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long hi = __hip_atomic_load(buf + 2 * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-            ok = __all((unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch);
+            const unsigned long long lo = __hip_atomic_load(buf + RES_GS * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(buf + RES_GS * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool own = RES_OWN_LOCAL && lane == srank;
+            v = own ? part : __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+            ok = __all(own || ((unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch));
             if (ok) break;
-            __builtin_amdgcn_s_sleep(1);
+            if (RES_POLL_SLEEP) __builtin_amdgcn_s_sleep(1);
         }
         const double ssub = wave_sum(v);                                      // uniform
         unsigned long long* buf2 = gran2 + (size_t)(epoch & 1u) * (8 * RES_GRAN2_STRIDE);
@@ -258,12 +272,13 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
                 if (lane < nsub) {
                     const unsigned long long lo = __hip_atomic_load(buf2 + RES_GRAN2_STRIDE * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long hi = __hip_atomic_load(buf2 + RES_GRAN2_STRIDE * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
-                    mine_ok = (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+                    const bool own = RES_OWN_LOCAL && srank == 0 && lane == sub;      // the run's leader knows its run's sum
+                    v = own ? ssub : __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                    mine_ok = own || ((unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch);
                 }
                 ok2 = __all(mine_ok);
                 if (ok2) break;
-                __builtin_amdgcn_s_sleep(1);
+                if (RES_POLL_SLEEP) __builtin_amdgcn_s_sleep(1);
             }
         }
         v = wave_sum_l63(v);
@@ -454,6 +469,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // registers are needed elsewhere): entry c = tid + u * 256 holds {global vertex index of the halo cell,
     // (byte offset in the float2 planes) / 8 | (byte offset in the float plane) / 4 << 16}
     uint2* htab = (uint2*)hlist;                                          // [RES_MAX_HALO]
+    // (with fewer than nine slots in use there are registers to spare: the entries stay in VGPRs and the update phase
+    //  starts its z loads without an LDS round trip)
+    constexpr bool HREG = NS <= RES_HALO_REG_SLOTS;
+    uint2 hreg[RES_HALO_PER_THREAD];
     {
         uint2 e[RES_HALO_PER_THREAD];
 #pragma unroll
@@ -481,8 +500,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
         __syncthreads();                             // every u16 entry has been read
 #pragma unroll
-        for (int u = 0; u < RES_HALO_PER_THREAD; ++u)
+        for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
             if (tid + u * RES_THREADS < RES_MAX_HALO) htab[tid + u * RES_THREADS] = e[u];     // 3 x 256 > 720 entries
+            hreg[u] = e[u];
+        }
         // (each thread reads back only what it wrote: no barrier needed)
     }
     static_assert(RES_TILES_PER_WG * LTILE < 65536 && LTILE % 2 == 0, "halo table packs 16-bit cell offsets");
@@ -527,14 +548,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         hier = !fast && wgs > 64 && (wgs & 63) == 0;
         if (!fast && rd.allow_fast && alive) {
             if (wave == 0) {
-                const unsigned long long* buf = gran_group + (size_t)1 * wgs * 2;     // parity of epoch 1
+                const unsigned long long* buf = gran_group + (size_t)1 * wgs * RES_GS;     // parity of epoch 1
                 bool remote = false, elsewhere = false;
                 for (int m = lane; m < wgs; m += 64) {
                     const bool nb = ((nbits[(m >> 5) & 15] >> (m & 31)) & 1u) != 0u;
                     const bool same_run = hier && (m >> 6) == (rank >> 6);
                     if (nb || same_run) {
-                        const unsigned long long lo = __hip_atomic_load(buf + 2 * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned long long hi = __hip_atomic_load(buf + 2 * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long lo = __hip_atomic_load(buf + RES_GS * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long hi = __hip_atomic_load(buf + RES_GS * m + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const double val = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
                         const double q2 = floor(val / 65536.0);
                         const bool other = (unsigned)(lo >> 32) != 1u || (unsigned)(hi >> 32) != 1u ||
@@ -730,7 +751,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             hz1[u] = 0.f;
             if (tid + u * RES_THREADS < nh) {
                 // uniform base + 32-bit byte offset formed here (precomputed 64-bit addresses would spill)
-                const unsigned gi = htab[tid + u * RES_THREADS].x;
+                const unsigned gi = HREG ? hreg[u].x : htab[tid + u * RES_THREADS].x;
                 hz2[u] = ld_sc1_f2((const float2*)((const char*)zO_b + (size_t)(gi * 8u)));
                 hz1[u] = ld_sc1_f((const float*)((const char*)zA_b + (size_t)(gi * 4u)));
             }
@@ -758,7 +779,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
             if (tid + u * RES_THREADS < nh) {
-                const unsigned pk = htab[tid + u * RES_THREADS].y;
+                const unsigned pk = HREG ? hreg[u].y : htab[tid + u * RES_THREADS].y;
                 float2* P = (float2*)((char*)lds + (pk & 0xffffu) * 8u);
                 float* A = (float*)((char*)lds + (pk >> 16) * 4u);
                 const float2 po = *P;

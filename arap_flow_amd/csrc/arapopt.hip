@@ -454,7 +454,7 @@ static int resident_deal(const int* ntiles, int nb, std::vector<ResWg>* map_out,
                 if (groups >= 8) { g = x + 8 * (j / wgs); rank = j % wgs; }
                 else { const int xper = 8 / groups; g = x / xper; rank = (x % xper) * XW + j; }
                 const int sb = set * groups + g;
-                if (sb < nb) map[(size_t)set * RES_WGS + i] = ResWg{sb, rank, wgs, 4 * g * wgs};
+                if (sb < nb) map[(size_t)set * RES_WGS + i] = ResWg{sb, rank, wgs, 2 * RES_GS * g * wgs};
             }
         inflight = nb < groups ? nb : groups;
     } else {
@@ -523,7 +523,7 @@ static int resident_deal(const int* ntiles, int nb, std::vector<ResWg>* map_out,
                     if (!first) continue;                        // dealt with its first bin
                     for (int q = 0; q < width[b]; ++q)
                         for (int j = 0; j < XW; ++j)
-                            map[(size_t)set * RES_WGS + (size_t)j * 8 + x + q] = ResWg{b, q * XW + j, wgs, 4 * ordinal};
+                            map[(size_t)set * RES_WGS + (size_t)j * 8 + x + q] = ResWg{b, q * XW + j, wgs, 2 * RES_GS * ordinal};
                     ordinal += wgs;
                     ++count;
                     continue;
@@ -533,7 +533,7 @@ static int resident_deal(const int* ntiles, int nb, std::vector<ResWg>* map_out,
                 for (int b : v) {
                     const int wgs = XW * need[b] / l2[k];        // >= need[b]; the widths of a bin sum to <= 64
                     for (int r = 0; r < wgs; ++r, ++j)
-                        map[(size_t)set * RES_WGS + (size_t)j * 8 + x] = ResWg{b, r, wgs, 4 * ordinal};
+                        map[(size_t)set * RES_WGS + (size_t)j * 8 + x] = ResWg{b, r, wgs, 2 * RES_GS * ordinal};
                     ordinal += wgs;
                     ++count;
                 }
@@ -558,6 +558,8 @@ static bool plan_resident_pack(Opt_Plan* p)
             int& m = ns[i / RES_WGS];
             m = t > m ? t : m;
         }
+    if (const char* fn = getenv("ARAPOPT_RES_NS"))               // experiments: run at least this many tile slots
+        for (int& m : ns) m = std::max(m, std::min(atoi(fn), (int)RES_SLOTS));
     const bool same = nsets == p->res_sets && ns == p->res_ns && map.size() == p->h_wgmap.size() &&
                       memcmp(map.data(), p->h_wgmap.data(), map.size() * sizeof(ResWg)) == 0;
     if (same) return false;
