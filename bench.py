@@ -356,10 +356,12 @@ def main():
                 out["warp_stage"] = {"error": str(e)[:200]}
         if a.stamps:
             arr = np.zeros((512, 8), np.uint64)
+            us = None
             if st.lib.ArapFlow_SolverStamps(fs.h, arr.ctypes.data) == 0:
                 o = arr.astype(np.float64)
                 used = o[:, 0] > 0
-                us = o[used, :5].mean(0) * 0.01 / lIter           # 100 MHz ticks -> us per iteration, mean over workgroups
+                us = o[used, :5].mean(0) * 0.01 / lIter if used.any() else None  # 100 MHz ticks -> us per iteration, mean over workgroups
+            if us is not None:
                 print(json.dumps({"stamps": {"us": dict(zip(["phaseA", "wait1", "phaseB", "wait2", "update"], [float(v) for v in us])),
                                              "wait_frac": float((us[1] + us[3]) / us.sum()), "workgroups": int(used.sum()),
                                              "note": "instrumented build (ARAPOPT_STAMPS=1), last resident launch; a workgroup that "

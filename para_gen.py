@@ -451,7 +451,13 @@ def parse(argv=None):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    parser.add_argument("--jobs", type=int, default=max(1, min(12, ncpu - 2)),
+    try:                                                   # a container's CPU quota (cgroup v2), if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    parser.add_argument("--jobs", type=int, default=max(1, min(96, ncpu - 2)),
                         help="worker processes for the per-pair front end and back end")
     parser.add_argument("--dm_bin", default=None, help="Path to the deep matching binary")
     parser.add_argument("--matches", default=None, help="directory of precomputed matches (instead of --dm_bin)")
