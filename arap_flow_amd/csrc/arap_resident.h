@@ -59,6 +59,12 @@ static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two wor
 #ifndef RES_HALO_REG_SLOTS
 #define RES_HALO_REG_SLOTS 8  // keep the decoded halo entries in registers when at most this many tile slots are in use
 #endif
+#ifndef RES_WREG_SLOTS
+#define RES_WREG_SLOTS 6      // keep the five per-vertex edge / fit weights in registers when at most this many slots are in use
+#endif
+#ifndef RES_WREG_FIT
+#define RES_WREG_FIT 1        // ... the fit weight too (0: only the four edge weights)
+#endif
 #ifndef RES_OWN_LOCAL
 #define RES_OWN_LOCAL 1       // a group wait takes the workgroup's own partial from its register, not from its granules
 #endif
@@ -393,6 +399,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     float ma_[NS], mo_[NS];
     unsigned fl[NS];
     int ibase[NS];                                     // SGPRs
+    // phase A weights an edge by wr^2 or +0 (fit term: wf^2 or +0) according to the vertex's flag bits.  With registers
+    // to spare (NS <= RES_WREG_SLOTS) the five weights per slot are formed once, here; otherwise from the flags in
+    // every iteration (two bit operations each: 10 of the 51 VALU instructions of a vertex)
+    constexpr bool WREG = NS <= RES_WREG_SLOTS;
+    float we[WREG ? NS : 1][5];
     const int loff = lx + W * ly;                      // this lane's vertex inside a tile: index = ibase + loff
 
     // LDS tile t: float2 P2[340] (px,py) | float2 CS[340] (cos,sin) | float PA[340]; cell = row*34 + col
@@ -458,6 +469,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     for (int j = 0; j < NS; ++j) {
         const unsigned f = fl[j];
         mo_[j] = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)];      // M^-1 of the Offset components
+        if (WREG) {
+            we[j][0] = keep_if<0>(f, wr2); we[j][1] = keep_if<1>(f, wr2); we[j][2] = keep_if<2>(f, wr2);
+            we[j][3] = keep_if<3>(f, wr2);
+            if (RES_WREG_FIT) we[j][4] = keep_if<4>(f, wf2);
+        }
         if (ly == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lx + 1);
         if (ly == RT_Y - 1 && (f & F_E2)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (RT_Y + 1) * LROW + lx + 1);
         if (lx == 0 && (f & F_E1)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (ly + 1) * LROW + 0);
@@ -646,7 +662,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                     const float2 qO = LqO[sj][E], cn2 = Lcn[sj][E];                                    \
                     const float qA = LqA[sj][E];                                                       \
                     const float cn = cn2.x, sn = cn2.y;                                                \
-                    const float w = keep_if<BITNO>(f, wr2);                                            \
+                    const float w = WREG ? we[WREG ? j : 0][BITNO] : keep_if<BITNO>(f, wr2);           \
                     const float2 e = pv - qO;                                                          \
                     const float2 t = fma2(make_float2(NQX, NQY), pa2, e);                              \
                     const float2 u = fma2(make_float2(NHX, NHY), make_float2(qA, qA), e + t);          \
@@ -664,7 +680,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 RES_EDGE(3, 3,      ci,  si,    cn,  sn,   -ci, -si)      // s=( 0,-1): q=(-ci,-si) h=(-cn,-sn)
 #undef RES_EDGE
                 {
-                    const float wf = keep_if<4>(f, wf2);
+                    const float wf = (WREG && RES_WREG_FIT) ? we[WREG ? j : 0][4] : keep_if<4>(f, wf2);
                     axy = fma2(make_float2(wf, wf), pv, axy);
                 }
                 const float ax = axy.x, ay = axy.y;
