@@ -105,7 +105,7 @@ struct ResDev {
     int force_fail;             // test hook (ARAPOPT_FORCE_RES_FAIL=1): behave as if a group wait had timed out
     int nowait;                 // diagnostic (ARAPOPT_RES_NOWAIT=1): one sweep per group wait, whatever the tags say (results are garbage:
                                 // measures the iteration without the waits, tools/res_stamps.py)
-    unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][8] summed s_memrealtime ticks
+    unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][16] summed s_memrealtime ticks / clocks
 };
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -165,10 +165,12 @@ __device__ __forceinline__ float ld_sc1_f(const float* p)
 // Returns the sum rounded to float in every thread; false on timeout.
 __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned long long* gran_group, int rank,
                                           int wgs, float* bcast /* LDS, 2 floats */, unsigned* err, float& out,
-                                          bool fast = false, double* out_d = nullptr, bool nowait = false)
+                                          bool fast = false, double* out_d = nullptr, bool nowait = false,
+                                          unsigned long long* tm = nullptr /* diagnostic: publish / poll / tail cycles */)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
+        unsigned long long c0 = tm ? __builtin_amdgcn_s_memtime() : 0ull, c1;
         // the whole group waits for the slowest publisher: this wave's few instructions go first on its SIMD
         __builtin_amdgcn_s_setprio(3);
         unsigned long long* buf = gran_group + (size_t)(epoch & 1u) * wgs * RES_GS;
@@ -186,7 +188,9 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
         }
         double v = 0.0;
         bool ok = false;
+        if (tm) { c1 = __builtin_amdgcn_s_memtime(); tm[0] += c1 - c0; c0 = c1; }
         for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {
+            if (tm) tm[3] += 1;
             v = 0.0;
             bool mine_ok = true;
             for (int m = lane; m < wgs; m += 64) {
@@ -203,6 +207,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
             if (ok) break;
             if (RES_POLL_SLEEP) __builtin_amdgcn_s_sleep(1);
         }
+        if (tm) { c1 = __builtin_amdgcn_s_memtime(); tm[1] += c1 - c0; c0 = c1; }
         v = wave_sum_l63(v);
         if (lane == 63) {
             // value with the sign bit of the second word as the "timed out" flag (one ds_write_b64); the slot
@@ -213,6 +218,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
             if (!ok) atomicExch(err, 0xDEAD0000u | (epoch & 0xffffu));
         }
         __builtin_amdgcn_s_setprio(0);
+        if (tm) { c1 = __builtin_amdgcn_s_memtime(); tm[2] += c1 - c0; }
     }
     __syncthreads();
     const float2 bc = *(const float2*)(bcast + 2 * (epoch & 1u));
@@ -332,6 +338,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 {
     static_assert(NS >= 1 && NS <= RES_SLOTS, "slots");
     unsigned long long tA = 0, tS1 = 0, tB = 0, tS2 = 0, tU = 0, t0 = 0, t1 = 0;
+    unsigned long long tm[4] = {0, 0, 0, 0}, tbs = 0;     // STAMPS: inside the group sums (shader clocks; wave 0)
 #define RES_STAMP(acc) do { if (STAMPS) { t1 = __builtin_amdgcn_s_memrealtime(); acc += t1 - t0; t0 = t1; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Group of this workgroup: dealt by the host (ResWg).  Speed only (never correctness): workgroups are dealt
@@ -693,8 +700,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #undef RES_LOAD_B
         float sigma;
         RES_STAMP(tA);
-        alive = hier ? group_sum_h(block_sum8(acc, wsum), 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
-                     : group_sum(block_sum8(acc, wsum), 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast, nullptr, rd.nowait != 0);
+        {
+            const unsigned long long cb = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
+            const double bs = block_sum8(acc, wsum);
+            if (STAMPS) tbs += __builtin_amdgcn_s_memtime() - cb;
+            alive = hier ? group_sum_h(bs, 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
+                         : group_sum(bs, 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast, nullptr, rd.nowait != 0,
+                                     STAMPS ? tm : nullptr);
+        }
         if (!alive) break;
         RES_STAMP(tS1);
         // ---------------- phase B: alpha, r, z, rho', delta ---------------------------------------------
@@ -749,8 +762,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         float rhoNew;
         RES_STAMP(tB);
         // (every storing wave drains inside block_sum8, before the workgroup barrier: R1)
-        alive = hier ? group_sum_h(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
-                     : group_sum(block_sum8<true>(acc, wsum), 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast, nullptr, rd.nowait != 0);
+        {
+            const unsigned long long cb = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
+            const double bs = block_sum8<true>(acc, wsum);
+            if (STAMPS) tbs += __builtin_amdgcn_s_memtime() - cb;
+            alive = hier ? group_sum_h(bs, 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
+                         : group_sum(bs, 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast, nullptr, rd.nowait != 0,
+                                     STAMPS ? tm : nullptr);
+        }
         if (!alive) break;
         RES_STAMP(tS2);
         float beta = 0.f;
@@ -807,7 +826,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         RES_STAMP(tU);
     }
     if (STAMPS && tid == 0) {
-        unsigned long long* o = rd.stamps + (size_t)blockIdx.x * 8;
+        unsigned long long* o = rd.stamps + (size_t)blockIdx.x * 16;
+        o[8] = tbs; o[9] = tm[0]; o[10] = tm[1]; o[11] = tm[2]; o[12] = tm[3];      // block sums, publish, poll, tail (clocks); sweeps
         o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; { unsigned pc = 0; for (int q = 0; q < 16; ++q) pc += __popc(nbits[q]); o[6] = (unsigned long long)nh | ((unsigned long long)pc << 32) | ((unsigned long long)*nremote << 48); } o[7] = (fast ? 1ull : 0ull) | (zfast ? 2ull : 0ull) | (hier ? 4ull : 0ull) | (subfast ? 8ull : 0ull);
     }
     if (!alive) return;

@@ -284,8 +284,8 @@ static void plan_enable_resident(Opt_Plan* p)
     if (sd && sd[0] == '1') {
         for (int ns = 1; ns <= RES_SLOTS; ++ns)
             HC(hipFuncSetAttribute(resident_kernel(true, ns), hipFuncAttributeMaxDynamicSharedMemorySize, RES_LDS_BYTES));
-        HC(hipMalloc(&p->rd.stamps, RES_WGS * 8 * sizeof(unsigned long long)));
-        HC(hipMemset(p->rd.stamps, 0, RES_WGS * 8 * sizeof(unsigned long long)));
+        HC(hipMalloc(&p->rd.stamps, RES_WGS * 16 * sizeof(unsigned long long)));
+        HC(hipMemset(p->rd.stamps, 0, RES_WGS * 16 * sizeof(unsigned long long)));
     }
     p->res_capable = true;
 }
@@ -1744,7 +1744,7 @@ int ArapFlow_SolverStamps(ArapFlow_Solver* s, uint64_t* out)
 {
     if (!s || !s->plan->rd.stamps) return -1;
     HC(hipStreamSynchronize(s->st->stream));
-    HC(hipMemcpy(out, s->plan->rd.stamps, RES_WGS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HC(hipMemcpy(out, s->plan->rd.stamps, RES_WGS * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -355,7 +355,7 @@ def main():
             except Exception as e:
                 out["warp_stage"] = {"error": str(e)[:200]}
         if a.stamps:
-            arr = np.zeros((512, 8), np.uint64)
+            arr = np.zeros((512, 16), np.uint64)
             us = None
             if st.lib.ArapFlow_SolverStamps(fs.h, arr.ctypes.data) == 0:
                 o = arr.astype(np.float64)

@@ -234,7 +234,7 @@ uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan);
  * further timeout, up to 1024; a checked success resets it).  Returns 1 once any launch of this state has given up. */
 int ArapFlow_ResidentFailed(Opt_State* state);
 /* Diagnostic only (env ARAPOPT_STAMPS=1 selects an instrumented build of the resident kernel): copies
- * out[512][8] = per workgroup {phase A, wait 1, phase B, wait 2, update} summed 100 MHz ticks of the
+ * out[512][16] = per workgroup {phase A, wait 1, phase B, wait 2, update} summed 100 MHz ticks of the
  * last resident launch, tiles per workgroup, halo cells.  Returns -1 when stamps are off. */
 int ArapFlow_SolverStamps(ArapFlow_Solver* s, uint64_t* out);
 

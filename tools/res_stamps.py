@@ -16,7 +16,7 @@ for b in range(B):
 fs.solve(B, 1, 2, L)
 torch.cuda.synchronize()
 t = time.perf_counter(); fs.solve(B, 1, 4, L); torch.cuda.synchronize(); dt = time.perf_counter() - t
-out = np.zeros((512, 8), np.uint64)
+out = np.zeros((512, 16), np.uint64)
 assert st.lib.ArapFlow_SolverStamps(fs.h, out.ctypes.data) == 0
 o = out.astype(np.float64)
 used = o[:, 0] > 0
@@ -28,6 +28,11 @@ print("workgroups active", used.sum(), "tiles/WG", o[used, 5].min(), o[used, 5].
 for n, col in zip(["phaseA", "wait1", "phaseB+drain", "wait2", "update"], us.T):
     print("%-14s mean %.2f  min %.2f  max %.2f us" % (n, col.mean(), col.min(), col.max()))
 print("sum of means %.2f us" % us.mean(0).sum())
+# inside the two group sums of an iteration (wave 0, shader clocks -> us at the clock the launch ran at, from the stamps)
+clk = o[used, 8:12] / (2.0 * L * 4)           # per sum; 4 launches... (the table holds the LAST launch only: / L)
+clk = o[used, 8:12] / (2.0 * L)
+print("per group sum, shader clocks: block sum %.0f  publish %.0f  poll %.0f  tail %.0f   sweeps per sum %.2f" % (
+    clk[:, 0].mean(), clk[:, 1].mean(), clk[:, 2].mean(), clk[:, 3].mean(), (o[used, 12] / (2.0 * L)).mean()))
 # per-workgroup view of one group (the workgroups of XCD 0: blockIdx & 7 == 0), sorted by tiles then phase A time
 idx = np.arange(512)
 g0 = used & ((idx & 7) == 0)
