@@ -81,7 +81,12 @@ constexpr int RES_GS = RES_GRAN_STRIDE;
 constexpr int RES_GRAN_L1 = 2 * RES_WGS * RES_GS;
 constexpr int RES_GRAN2_STRIDE = 16;            // u64 per second-level granule pair: one 128-byte line per XCD run
 constexpr int RES_GRAN2_GROUP = 2 * 8 * RES_GRAN2_STRIDE;
-constexpr int RES_GRAN_PER_LAUNCH = RES_GRAN_L1 + 4 * RES_GRAN2_GROUP;
+// third region: a write-through copy of every workgroup's granules, same offsets as the first (group_sum_x)
+constexpr int RES_GRAN_X = RES_GRAN_L1 + 4 * RES_GRAN2_GROUP;
+constexpr int RES_GRAN_PER_LAUNCH = RES_GRAN_X + RES_GRAN_L1;
+#ifndef RES_FLAT_MAX_RUNS
+#define RES_FLAT_MAX_RUNS 2   // groups of up to this many XCD runs sum with group_sum_x (one hop), wider ones in two levels
+#endif
 
 // One entry per workgroup of a launch, written by the host (arapopt.hip: plan_resident_pack): which solve the
 // workgroup works on, its rank in that solve's group, the group's size and where the group's granules start.
@@ -103,6 +108,7 @@ struct ResDev {
     const ResWg* wgmap;         // [RES_WGS] of this launch
     int allow_fast;             // 0: always use the write-through (placement independent) store flavour
     int force_fail;             // test hook (ARAPOPT_FORCE_RES_FAIL=1): behave as if a group wait had timed out
+    int flat_runs;              // groups of up to this many XCD runs use group_sum_x (ARAPOPT_FLAT_RUNS, default RES_FLAT_MAX_RUNS)
     int nowait;                 // diagnostic (ARAPOPT_RES_NOWAIT=1): one sweep per group wait, whatever the tags say (results are garbage:
                                 // measures the iteration without the waits, tools/res_stamps.py)
     unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][16] summed s_memrealtime ticks / clocks
@@ -306,6 +312,70 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
     return bc.y != 0.0f;
 }
 
+// One-hop sum for a group that spans a FEW XCDs (nsub <= RES_FLAT_MAX_RUNS runs of 64 ranks).  The two levels above cost
+// two latency chains in sequence (a run's all-gather through its L2, then the leader's write-through store and every
+// workgroup's poll of it through the fabric: 2.1-2.3 us measured).  Here every workgroup publishes its partial TWICE --
+// into its run's buffer (plain stores when the run shares an XCD: stays in that L2) and, write-through, into a second
+// buffer that every XCD can read -- and polls, in the same sweep, its own run's granules from the first buffer and the
+// other runs' from the second.  Lane k adds ranks k, k + 64, ... in rank order, then the fixed DPP tree: the same bits
+// in every workgroup.  The fabric carries (nsub - 1) x 64 granule pairs per poller and sweep: fine for 2 runs (128
+// pollers x 1 KB), too much for 4 or 8 (round 1 measured 3.4 us for a flat gather over 256 workgroups).
+// z visibility: a workgroup's z stores (write-through where a reader sits on another XCD) are drained before either copy
+// of its granule is stored.
+__device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigned long long* gran_group,
+                                            unsigned long long* granx_group, int rank, int wgs, float* bcast, unsigned* err,
+                                            float& out, bool subfast)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        const int sub = rank >> 6, srank = rank & 63, nsub = wgs >> 6;
+        unsigned long long* bufl = gran_group + (size_t)sub * (128 * RES_GS) + (size_t)(epoch & 1u) * (64 * RES_GS);
+        unsigned long long* bufx = granx_group + (size_t)(epoch & 1u) * wgs * RES_GS;      // [wgs] pairs, rank order
+        part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
+                                __builtin_amdgcn_readfirstlane(__double2loint(part)));
+        if (lane < 4) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(part);
+            const unsigned hw = (lane & 1) == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+            const unsigned long long gv = ((unsigned long long)epoch << 32) | hw;
+            if (lane < 2) {
+                if (subfast)
+                    __hip_atomic_store(bufl + srank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_store(bufl + srank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(bufx + rank * RES_GS + (lane & 1), gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        double v = 0.0;
+        bool ok = false;
+        for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {
+            v = 0.0;
+            bool mine_ok = true;
+            for (int r = 0; r < nsub; ++r) {                          // rank r * 64 + lane: own run locally, others remotely
+                const unsigned long long* src = r == sub ? bufl + RES_GS * lane : bufx + RES_GS * (r * 64 + lane);
+                const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine_ok = mine_ok && (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
+                v += __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+            }
+            ok = __all(mine_ok);
+            if (ok) break;
+            if (RES_POLL_SLEEP) __builtin_amdgcn_s_sleep(1);
+        }
+        v = wave_sum_l63(v);
+        if (lane == 63) {
+            *(float2*)(bcast + 2 * (epoch & 1u)) = make_float2((float)v, ok ? 1.0f : 0.0f);
+            if (!ok) atomicExch(err, 0xDEAD4000u | (epoch & 0x3fffu));
+        }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+    const float2 bc = *(const float2*)(bcast + 2 * (epoch & 1u));
+    out = bc.x;
+    return bc.y != 0.0f;
+}
+
 // block-wide sum of a double over the 4 wavefronts; result valid in wave 0 lane 0
 template <bool DRAIN = false>
 __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 doubles */)
@@ -369,6 +439,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     unsigned* nbits = (unsigned*)(wsum + 10);                             // [16] bitmap: ranks owning my halo vertices
     unsigned* nremote = nbits + 16;                                       // [1] some of them sit on another XCD
     unsigned long long* gran_group = rd.gran + me.gran;
+    unsigned long long* granx_group = rd.gran + RES_GRAN_X + me.gran;
 
     const int nt = rd.ntiles[b];
     // this workgroup's run of the frame's active-tile list: nt tiles dealt evenly, the first nt % wgs ranks
@@ -551,6 +622,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // the ids are all equal iff  wgs * sum(xcc^2) == (sum xcc)^2.
     bool fast = false, zfast = false;                  // store flavour of the granules / of this workgroup's z
     bool hier = false, subfast = false;                // two-level sums for a group that spans XCDs (group_sum_h)
+    bool hierx = false;                                // ... or the one-hop form for a group of few runs (group_sum_x)
     // second-level granules of a group that spans XCDs: it starts at an even bin (blockIdx & 7) - (rank >> 6)
     unsigned long long* const gran2 =
         rd.gran + RES_GRAN_L1 + ((((int)(blockIdx.x & 7u) - (me.rank >> 6)) >> 1) & 3) * RES_GRAN2_GROUP;
@@ -569,6 +641,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         // workgroups of this XCD run really share an XCD.  The epoch-1 granules still hold every workgroup's id (a
         // granule that a faster workgroup has already reused carries another tag and counts as "elsewhere").
         hier = !fast && wgs > 64 && (wgs & 63) == 0;
+        hierx = hier && (wgs >> 6) <= rd.flat_runs;
         if (!fast && rd.allow_fast && alive) {
             if (wave == 0) {
                 const unsigned long long* buf = gran_group + (size_t)1 * wgs * RES_GS;     // parity of epoch 1
@@ -704,9 +777,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             const unsigned long long cb = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
             const double bs = block_sum8(acc, wsum);
             if (STAMPS) tbs += __builtin_amdgcn_s_memtime() - cb;
-            alive = hier ? group_sum_h(bs, 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
-                         : group_sum(bs, 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast, nullptr, rd.nowait != 0,
-                                     STAMPS ? tm : nullptr);
+            alive = hierx ? group_sum_x(bs, 2u * l + 2u, gran_group, granx_group, rank, wgs, bcast, rd.err, sigma, subfast)
+                  : hier  ? group_sum_h(bs, 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
+                          : group_sum(bs, 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast, nullptr, rd.nowait != 0,
+                                      STAMPS ? tm : nullptr);
         }
         if (!alive) break;
         RES_STAMP(tS1);
@@ -766,9 +840,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             const unsigned long long cb = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
             const double bs = block_sum8<true>(acc, wsum);
             if (STAMPS) tbs += __builtin_amdgcn_s_memtime() - cb;
-            alive = hier ? group_sum_h(bs, 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
-                         : group_sum(bs, 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast, nullptr, rd.nowait != 0,
-                                     STAMPS ? tm : nullptr);
+            alive = hierx ? group_sum_x(bs, 2u * l + 3u, gran_group, granx_group, rank, wgs, bcast, rd.err, rhoNew, subfast)
+                  : hier  ? group_sum_h(bs, 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
+                          : group_sum(bs, 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast, nullptr, rd.nowait != 0,
+                                      STAMPS ? tm : nullptr);
         }
         if (!alive) break;
         RES_STAMP(tS2);

@@ -277,6 +277,10 @@ static void plan_enable_resident(Opt_Plan* p)
         p->rd.allow_fast = (nf && nf[0] == '1') ? 0 : 1;
     }
     {
+        const char* fr = getenv("ARAPOPT_FLAT_RUNS");           // experiments: 0 = always two levels, 4 / 8 = wider one-hop sums
+        p->rd.flat_runs = fr ? atoi(fr) : RES_FLAT_MAX_RUNS;
+    }
+    {
         const char* nw = getenv("ARAPOPT_RES_NOWAIT");          // diagnostic: iteration time without the group waits
         p->rd.nowait = (nw && nw[0] == '1') ? 1 : 0;
     }

@@ -39,6 +39,10 @@ class State:
         if not self.handle:
             raise RuntimeError("Opt_NewState failed")
 
+    def use_own_stream(self):
+        """non-blocking compute stream owned by the library (hosts that overlap copies with solves)"""
+        self.lib.ArapFlow_UseOwnStream(self.handle)
+
     def set_stream(self, stream=None):
         self.lib.ArapFlow_SetStream(self.handle, C.c_void_p(stream.cuda_stream if stream is not None else 0))
 
@@ -308,6 +312,32 @@ class FrameSolver:
         rc = self.lib.ArapFlow_SolverSolve(self.h, n, num_iter, non_linear_iter, linear_iter)
         if rc != 0:
             raise ValueError("ArapFlow_SolverSolve: bad arguments")
+
+    def solve_async(self, nframes=None, num_iter=19, non_linear_iter=8, linear_iter=400, warp=True, download=True):
+        """ArapFlow_SolverSolveAsync: enqueue schedule (+ warp, + download into pinned host buffers), do not wait"""
+        n = self.batch if nframes is None else nframes
+        rc = self.lib.ArapFlow_SolverSolveAsync(self.h, n, num_iter, non_linear_iter, linear_iter, int(warp), int(download))
+        if rc != 0:
+            raise ValueError("ArapFlow_SolverSolveAsync: bad arguments")
+
+    def wait(self):
+        rc = self.lib.ArapFlow_SolverWait(self.h)
+        if rc != 0:
+            raise RuntimeError("ArapFlow_SolverWait failed: %d" % rc)
+
+    def host_results(self, slot):
+        """views (no copy) of the pinned result buffers of a `download` solve: valid until this solver's next solve"""
+        H, W = self.H, self.W
+        pf, pr, pm = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rc = self.lib.ArapFlow_SolverHostResults(self.h, slot, C.byref(pf), C.byref(pr), C.byref(pm))
+        if rc != 0:
+            raise ValueError("ArapFlow_SolverHostResults: no downloaded results for slot %d" % slot)
+        def view(ptr, ctype, shape):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).reshape(shape)
+        return dict(flow=view(pf, C.c_float, (H, W, 2)),
+                    warped_rgb=view(pr, C.c_uint8, (H, W, 3)) if pr.value else None,
+                    warped_mask=view(pm, C.c_uint8, (H, W)))
 
     def warp(self, nframes=None):
         n = self.batch if nframes is None else nframes

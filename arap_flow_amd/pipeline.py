@@ -78,11 +78,13 @@ def deform_list(state, lines, num_iter=19, non_linear_iter=8, linear_iter=400, m
     """arap_deform over a list (main.cpp:223-238).  Frames of equal size are solved together: the library gives
     every solve a group of the resident launch's workgroups sized by its active tiles, and a launch costs the same
     however full it is, so frames are added to a batch while they still fit ONE launch (8 DAVIS-shaped 854x480
-    frames, ~21 --multseg segment solves); FILL_MIN frames per call when the resident path does not apply.
-    Host work overlaps the GPU: list lines are decoded ahead by worker threads and a finished batch is encoded and
-    written while the next one is being solved."""
+    frames, ~24 --multseg segment solves); FILL_MIN frames per call when the resident path does not apply.
+    The GPU does not wait for the host (the structure of arap_flow_amd/host/arap_deform.cpp): two solver objects
+    alternate; while one batch is solved the next is decoded (worker threads) and uploaded into the other object, and
+    the previous batch's results are read from pinned memory and encoded (worker threads)."""
     from concurrent.futures import ThreadPoolExecutor
     from . import opt
+    state.use_own_stream()
     ahead = 2 * max_batch
     with ThreadPoolExecutor(max_workers=8) as pool:
         loading = {}
@@ -94,20 +96,42 @@ def deform_list(state, lines, num_iter=19, non_linear_iter=8, linear_iter=400, m
             return loading[k].result()
 
         writing = []
-        i = 0
-        solver, size = None, None
+        lanes = [dict(solver=None, batch=[]), dict(solver=None, batch=[])]
+        size = None
+
+        def drain(lane):
+            """wait for the lane's solve, hand copies of its results to the writer threads"""
+            if not lane["batch"]:
+                return
+            lane["solver"].wait()
+            for b, ln in enumerate(lane["batch"]):
+                r = lane["solver"].host_results(b)
+                res = dict(flow=r["flow"].copy(), warped_rgb=r["warped_rgb"].copy(), warped_mask=r["warped_mask"].copy())
+                writing.append(pool.submit(_save_result, ln, res))
+                if verbose:
+                    print("Saved")                                          # main.cpp:159
+            lane["batch"] = []
+            while len(writing) > 48:
+                writing.pop(0).result()
+
+        i, cur = 0, 0
         while i < len(lines):
             rgb0 = frame_at(i)[0]
             H, W = rgb0.shape[:2]
             if size != (W, H):
-                if solver is not None:
-                    if verbose:
-                        print("Warning: Input image has different size to one in the prebuilt plan.\n"
-                              "To avoid re-building the plan and to save time, put images of the same size in the "
-                              "same list.\nStarting to re-build plan...")      # CombinedSolver.h:151-153
-                    solver.close()
-                solver = opt.FrameSolver(state, W, H, batch=max_batch)
+                for lane in lanes:
+                    drain(lane)
+                    if lane["solver"] is not None:
+                        lane["solver"].close()
+                if size is not None and verbose:
+                    print("Warning: Input image has different size to one in the prebuilt plan.\n"
+                          "To avoid re-building the plan and to save time, put images of the same size in the "
+                          "same list.\nStarting to re-build plan...")      # CombinedSolver.h:151-153
+                for lane in lanes:
+                    lane["solver"] = opt.FrameSolver(state, W, H, batch=max_batch)
                 size = (W, H)
+            lane, other = lanes[cur], lanes[cur ^ 1]
+            solver = lane["solver"]
             batch = []
             j = i
             while j < len(lines) and len(batch) < max_batch:
@@ -126,20 +150,18 @@ def deform_list(state, lines, num_iter=19, non_linear_iter=8, linear_iter=400, m
                 batch.append(ln)
                 del loading[j]                                  # the device holds it now
                 j += 1
-            solver.solve(len(batch), num_iter, non_linear_iter, linear_iter)
-            solver.warp(len(batch))
-            results = [solver.results(b) for b in range(len(batch))]      # blocks until the GPU is done
-            for f in writing:
-                f.result()
-            writing = [pool.submit(_save_result, ln, r) for ln, r in zip(batch, results)]
-            if verbose:
-                for _ in batch:
-                    print("Saved")                                          # main.cpp:159
+            solver.solve_async(len(batch), num_iter, non_linear_iter, linear_iter, warp=True, download=True)
+            lane["batch"] = batch
+            drain(other)                                        # the previous batch, while this one is being solved
+            cur ^= 1
             i = j
+        for lane in (lanes[cur], lanes[cur ^ 1]):
+            drain(lane)
         for f in writing:
             f.result()
-        if solver is not None:
-            solver.close()
+        for lane in lanes:
+            if lane["solver"] is not None:
+                lane["solver"].close()
 
 
 def warp_files(state, rgb_path, mask_path, flo_path, out_rgb_path, out_mask_path):

@@ -209,7 +209,7 @@ def test_resident_kernel_without_the_xcd_fast_paths(tmp_path):
         "from arap_flow_amd import opt, synth\n"
         "from oracle import oracle as orc\n"
         "st = opt.State()\n"
-        "for (W, H, full) in ((160, 96, False), (854, 480, True)):\n"
+        "for (W, H, full) in ((160, 96, False), (640, 360, True), (854, 480, True)):\n"      # 1 XCD, 2 XCDs (one-hop sums), 4 XCDs (two-level sums)
         "    f = synth.make_frame(W, H, seed=5, full_mask=full)\n"
         "    fs = opt.FrameSolver(st, W, H, batch=1); fs.set_frame(0, f['mask_red'], f['constraints'])\n"
         "    fs.solve(1, 1, 2, 20); r = fs.results(0, want_rgb=False)\n"

@@ -9,6 +9,8 @@ For the configuration it runs, each as its own process with the program directly
   3. rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes, MI355X_MICROARCH.md "HBM"), and two SQ passes
      on a short schedule (1 ramp step x 2 GN steps x 400 PCG iterations)
   4. the instrumented build of the resident kernel (ARAPOPT_STAMPS=1): share of an iteration spent in the two group waits
+  5. python3 bench.py <args> again with the counters of 2-4 in place: that line (traffic, hbm_frac_by_counters,
+     valu_issue_frac, wait_frac filled in) is the one kept as <round>_<NAME>_bench.json
 and condenses 2-4 into <round>_<NAME>_counters.json (all three under gpurun_out/profiles/, the directory that travels
 back from the GPU box; copied into profiles/ by hand), which bench.py reads back from profiles/ for `roofline.traffic`,
 `hbm_frac_by_counters`, `valu_issue_frac`, `wait_frac` -- keyed by the configuration's signature and the hash of the
@@ -158,6 +160,16 @@ def main():
                     rec["stamps"] = json.loads(ln)["stamps"]
     open(pre + "_counters.json", "w").write(json.dumps(rec, indent=1) + "\n")
     print("wrote", pre + "_counters.json")
+    # ---- 5. the bench line once more, now that its counters exist: the committed line carries traffic / utilisations ----
+    if "bench" not in a.skip:
+        os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+        shutil.copy(pre + "_counters.json", os.path.join(ROOT, "profiles", os.path.basename(pre) + "_counters.json"))
+        log = os.path.join(outdir, "bench_final.log")
+        if run(["python3", "bench.py"] + args, log) == 0:
+            lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
+            if lines:
+                bench_line = json.loads(lines[-1])
+                open(pre + "_bench.json", "w").write(lines[-1] + "\n")
     if bench_line:
         print(json.dumps({k: bench_line[k] for k in ("value", "ms_per_step", "roofline") if k in bench_line})[:900])
 
