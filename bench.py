@@ -261,8 +261,13 @@ def main():
         r0 = None
         if not a.no_kernel_timing:
             tl = min(lIter, 400)
+            G = 8                                      # Gauss-Newton steps timed: 2 solves x 4 steps of tl PCG iterations
             st.set_kernel_timing(True)
-            fs.solve(S, 1, 4, tl)                      # 4 Gauss-Newton steps of tl PCG iterations
+            fs.solve(S, 1, 1, tl)                      # (one un-graphed step first: the records of a cold launch are dropped)
+            torch.cuda.synchronize()
+            st.set_kernel_timing(True)                 # clears the records
+            for _ in range(2):
+                fs.solve(S, 1, 4, tl)
             torch.cuda.synchronize()
             kt = {k: st.kernel_time(k) for k in ("PCGResident", "PCGStepA", "PCGStepB")}
             st.set_kernel_timing(False)
@@ -272,9 +277,9 @@ def main():
                 tot_ms, n = kt["PCGResident"]
                 # one launch = all `tl` PCG iterations of one GN step for the frames in flight;
                 # algorithmic bytes: 160 B per active vertex per PCG iteration
-                bytes_total = 160.0 * n_act_total * tl * 4
+                bytes_total = 160.0 * n_act_total * tl * G
                 ach = bytes_total / (tot_ms * 1e-3) / 1e9
-                frames_per_launch = S * 4.0 / n
+                frames_per_launch = S * float(G) / n
                 rl = {
                     "bound": "valu_issue+group_wait", "kernel": "k_pcg_resident", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "equivalent_GBs": ach,

@@ -83,6 +83,8 @@ def main():
     ap.add_argument("name", choices=sorted(CONFIGS))
     ap.add_argument("--round", default="r02")
     ap.add_argument("--skip", nargs="*", default=[], choices=["bench", "stats", "pmc", "stamps"])
+    ap.add_argument("--bench-only", action="store_true",
+                    help="re-run only the bench line (the counters record under profiles/ is kept and read back by it)")
     ap.add_argument("extra", nargs="*")
     a = ap.parse_args()
     os.chdir("/tmp")
@@ -97,6 +99,14 @@ def main():
     pre = os.path.join(prof, "%s_%s" % (a.round, a.name))
     rec = {"config": a.name, "bench_args": args, "source_hash": profile_key.source_hash(),
            "made_by": "tools/collect_profile.py " + a.name, "unix_time": int(time.time())}
+    if a.bench_only:
+        log = os.path.join(outdir, "bench_final.log")
+        if run(["python3", "bench.py"] + args, log) == 0:
+            lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
+            if lines:
+                open(pre + "_bench.json", "w").write(lines[-1] + "\n")
+                print(lines[-1][:300])
+        return
 
     # ---- 1. the bench line ---------------------------------------------------------------------------------------
     bench_line = None
