@@ -65,6 +65,9 @@ struct PlanDev {
     // nodes: reduction slot 0 of every frame (rho_0, written by k_gn_init) and the granules of all launches
     unsigned long long* res_gran;
     int res_gran_n;          // u64 entries to zero; 0 = the two-kernel path (host memsets all slots of `red`)
+    // list launches of the per-step kernels (arap_kernels.h: vidx): every frame's active 64x4 tiles; NULL = whole grid
+    const int* t64list;      // [batch][tilesX * tilesY]
+    const int* t64n;         // [batch]
 };
 
 // ---- cos/sin: same operation list as oracle/arap_oracle.c:arap_sincos_spec ----------------------

@@ -18,20 +18,39 @@ namespace arap {
 struct VIdx {
     int x, y, i, b;       // vertex coords, linear index within the frame, slot
     size_t g;             // b*N + i : index into the plan-owned [batch][N] images
-    unsigned wg;          // linear workgroup index within the frame
+    unsigned wg;          // linear index of the workgroup's 64x4 tile within the frame
+    unsigned lb, nlb;     // linear index of the workgroup within the frame's launch, workgroups per frame in the launch
     bool in;              // inside the image
+    bool tile_ok;         // the workgroup has a tile (list launches: blockIdx.x < the frame's list length)
 };
 
+// Two launch shapes: grid (tilesX, tilesY, frames) over the whole tile grid, or -- pd.t64list set -- grid (n, 1, frames)
+// over the frames' lists of ACTIVE 64x4 tiles (frame solver on the resident path: the per-step kernels around the
+// resident launch then touch a quarter of a DAVIS-shaped frame instead of all of it).
 __device__ __forceinline__ VIdx vidx(const PlanDev& pd)
 {
     VIdx v;
-    v.x = blockIdx.x * TILE_X + threadIdx.x;
-    v.y = blockIdx.y * TILE_Y + threadIdx.y;
     v.b = blockIdx.z;
-    v.in = v.x < pd.W && v.y < pd.H;
+    int tx = blockIdx.x, ty = blockIdx.y;
+    v.tile_ok = true;
+    if (pd.t64list) {
+        const int n = pd.t64n[v.b];
+        v.tile_ok = (int)blockIdx.x < n;
+        const int t = v.tile_ok ? pd.t64list[(size_t)v.b * pd.tilesX * pd.tilesY + blockIdx.x] : 0;
+        ty = t / pd.tilesX;
+        tx = t - ty * pd.tilesX;
+        v.lb = blockIdx.x;
+        v.nlb = gridDim.x;
+    } else {
+        v.lb = blockIdx.y * gridDim.x + blockIdx.x;
+        v.nlb = gridDim.x * gridDim.y;
+    }
+    v.x = tx * TILE_X + threadIdx.x;
+    v.y = ty * TILE_Y + threadIdx.y;
+    v.in = v.tile_ok && v.x < pd.W && v.y < pd.H;
     v.i = v.x + pd.W * v.y;
     v.g = (size_t)v.b * pd.N + (v.in ? v.i : 0);
-    v.wg = blockIdx.y * gridDim.x + blockIdx.x;
+    v.wg = (unsigned)(ty * pd.tilesX + tx);
     return v;
 }
 
@@ -57,13 +76,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
         pd.cs[v.g] = sincos_spec(sl.A[v.i]);
     }
     const int any = __syncthreads_or((int)(f & F_ACT));
-    if (threadIdx.x == 0 && threadIdx.y == 0)
+    if (v.tile_ok && threadIdx.x == 0 && threadIdx.y == 0)
         pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
     if (pd.res_gran_n) {
         const int t = threadIdx.y * TILE_X + threadIdx.x;
-        if (v.wg == 0 && t < NSHARD) pd.red[(size_t)v.b * pd.nslots * NSHARD + t] = 0.0;
+        if (v.lb == 0 && t < NSHARD) pd.red[(size_t)v.b * pd.nslots * NSHARD + t] = 0.0;
         if (v.b == 0)
-            for (int i = (int)v.wg * (TILE_X * TILE_Y) + t; i < pd.res_gran_n; i += (int)(gridDim.x * gridDim.y) * (TILE_X * TILE_Y))
+            for (int i = (int)v.lb * (TILE_X * TILE_Y) + t; i < pd.res_gran_n; i += (int)v.nlb * (TILE_X * TILE_Y))
                 pd.res_gran[i] = 0ull;
     }
 }

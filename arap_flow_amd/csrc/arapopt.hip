@@ -140,6 +140,12 @@ struct Opt_Plan {
     std::vector<uint8_t> h_tiles_valid;
     std::vector<std::vector<int>> h_tilepos, h_bandx0;
     uint8_t* d_resact = nullptr;    // [rtX * rtY] drop-in analysis: 32x8 tiles (fixed grid) that hold an active vertex
+    // frame solver: every slot's active 64x4 tiles, for the list launches of k_gn_prep / k_gn_init / k_gn_update
+    int* d_t64list = nullptr;       // [batch][tilesX * tilesY]
+    int* d_t64n = nullptr;          // [batch]
+    std::vector<std::vector<int>> h_t64;
+    std::vector<int> h_t64n;
+    int g_maxn = -1;                // list length the captured graph was built for
     int res_tiles_all = 0;          // 32x8 tiles of the whole grid (share of active tiles: plan_active_tiles_majority)
     bool hole_pending = false;      // test hook ARAPOPT_FORCE_RES_FAIL=2: the next table upload leaves one workgroup out
     ResWg* d_wgmap = nullptr;       // [batch][RES_WGS]: one table per resident launch of a GN step
@@ -204,6 +210,8 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     p->h_tiles_valid.assign(batch, 0);
     p->h_tilepos.assign(batch, std::vector<int>());
     p->h_bandx0.assign(batch, std::vector<int>());
+    p->h_t64.assign(batch, std::vector<int>());
+    p->h_t64n.assign(batch, 0);
     return p;
 }
 
@@ -622,6 +630,7 @@ static void plan_free(Opt_Plan* p)
     if (p->res_block) (void)hipFree(p->res_block);
     if (p->rd.stamps) (void)hipFree(p->rd.stamps);
     if (p->d_notgrid) (void)hipFree(p->d_notgrid);
+    if (p->d_t64list) (void)hipFree(p->d_t64list);
     if (p->lm_block) (void)hipFree(p->lm_block);
     if (p->pd.lmred) (void)hipFree(p->pd.lmred);
     if (p->block) (void)hipFree(p->block);
@@ -757,8 +766,19 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
         // reduction slots 0 .. 2L of every active frame (contiguous because slot stride is nslots)
         HC(hipMemsetAsync(p->pd.red, 0, (size_t)p->nb * p->pd.nslots * NSHARD * sizeof(double), s));
     }
-    LAUNCH(p, s, "GNPrep", k_gn_prep, g, b, pd);
-    LAUNCH(p, s, "PCGInit1", k_gn_init, g, b, p->pd);
+    // frame solver on the resident path: the per-step kernels visit the frames' active 64x4 tiles only
+    const bool lists = res && p->res_frames && p->d_t64list != nullptr;
+    PlanDev pdl = p->pd;
+    dim3 gl = g;
+    if (lists) {
+        int maxn = 1;
+        for (int k = 0; k < p->nb; ++k) maxn = std::max(maxn, p->h_t64n[k]);
+        pd.t64list = pdl.t64list = p->d_t64list;
+        pd.t64n = pdl.t64n = p->d_t64n;
+        gl = dim3((unsigned)maxn, 1, (unsigned)p->nb);
+    }
+    LAUNCH(p, s, "GNPrep", k_gn_prep, gl, b, pd);
+    LAUNCH(p, s, "PCGInit1", k_gn_init, gl, b, pdl);
     if (res) {
         // all L iterations in one launch, state on chip (arap_resident.h)
         ResDev rd = p->rd;
@@ -783,7 +803,7 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
                 LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
         }
     }
-    LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, g, b, p->pd);
+    LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl);
 }
 
 static void plan_gn_step(Opt_Plan* p)
@@ -814,7 +834,10 @@ static void plan_gn_step(Opt_Plan* p)
     }
     // the captured launches bake in the path (resident: number of launches; two-kernel: phase-A variant)
     const int res_now = res ? p->res_sets : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p)) - 16 * (int)p->grid_u;
-    if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now) {
+    int maxn_now = 0;
+    if (res && p->res_frames && p->d_t64list)
+        for (int k = 0; k < p->nb; ++k) maxn_now = std::max(maxn_now, p->h_t64n[k]);
+    if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now || p->g_maxn != maxn_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
         enqueue_gn_step(p, st->cap);
@@ -823,6 +846,7 @@ static void plan_gn_step(Opt_Plan* p)
         p->g_l = p->sp.lIterations;
         p->g_nb = p->nb;
         p->g_res = res_now;
+        p->g_maxn = maxn_now;
     }
     HC(hipGraphLaunch(p->gexec, st->stream));
 }
@@ -1504,6 +1528,12 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
     plan_enable_resident(s->plan);
     s->plan->res_frames = s->plan->res_capable;
     s->plan->grid_u = true;                                   // k_frame_reset writes U = the pixel grid
+    {
+        const size_t T = (size_t)s->plan->pd.tilesX * s->plan->pd.tilesY;
+        HC(hipMalloc(&s->plan->d_t64list, (batch * T + batch) * sizeof(int)));
+        HC(hipMemsetAsync(s->plan->d_t64list, 0, (batch * T + batch) * sizeof(int), st->stream));
+        s->plan->d_t64n = s->plan->d_t64list + batch * T;
+    }
     const size_t N = s->N;
     const size_t sz2 = align_up(N * sizeof(float2), 256), sz1 = align_up(N * sizeof(float), 256);
     const size_t szb = align_up(N, 256), sz3 = align_up(3 * N, 256), szk = align_up(N * 8, 256);
@@ -1596,6 +1626,31 @@ int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rg
     build_resident_tiles(mask_red, W, H, true, tiles, bandx0, &na);
     s->nactive[slot] = na;
     plan_upload_tiles(s->plan, (int)slot, tiles, bandx0, s->copy);
+    {
+        // active 64x4 tiles (list launches of the per-step kernels).  Those kernels then rewrite flags / tile activity
+        // inside the listed tiles only, so what an earlier frame left in this slot is cleared here.
+        Opt_Plan* p = s->plan;
+        const int tX = p->pd.tilesX, tY = p->pd.tilesY;
+        std::vector<int>& l64 = p->h_t64[slot];
+        l64.clear();
+        for (int ty = 0; ty < tY; ++ty)
+            for (int tx = 0; tx < tX; ++tx) {
+                bool any = false;
+                for (int y = ty * TILE_Y; y < H && y < (ty + 1) * TILE_Y && !any; ++y) {
+                    const uint8_t* row = mask_red + (size_t)W * y;
+                    for (int x = tx * TILE_X; x < W && x < (tx + 1) * TILE_X; ++x)
+                        if (row[x] == 0) { any = true; break; }
+                }
+                if (any) l64.push_back(ty * tX + tx);
+            }
+        p->h_t64n[slot] = (int)l64.size();
+        const size_t T = (size_t)tX * tY;
+        if (!l64.empty())
+            HC(hipMemcpyAsync(p->d_t64list + slot * T, l64.data(), l64.size() * sizeof(int), hipMemcpyHostToDevice, s->copy));
+        HC(hipMemcpyAsync(p->d_t64n + slot, &p->h_t64n[slot], sizeof(int), hipMemcpyHostToDevice, s->copy));
+        HC(hipMemsetAsync(p->pd.flags + (size_t)slot * N, 0, N, s->copy));
+        HC(hipMemsetAsync(p->pd.tileact + (size_t)slot * T, 0, T, s->copy));
+    }
     const FrameDev& f = s->hfr[slot];
     HC(hipMemcpyAsync(f.T, T, N * sizeof(float2), hipMemcpyHostToDevice, s->copy));
     HC(hipMemcpyAsync(f.mask, smask, N, hipMemcpyHostToDevice, s->copy));
