@@ -56,6 +56,7 @@ SYMBOLS = [
     ("ArapFlow_PlanResidentLaunches", C.c_uint64, [_VP]),
     ("ArapFlow_SolverLaunchesFor", _I, [_VP, C.c_uint]),
     ("ArapFlow_ResidentDeal", _I, [C.POINTER(C.c_int), C.c_uint, C.POINTER(C.c_int), C.c_uint]),
+    ("ArapFlow_ResidentTiles", _I, [_VP, _U, _U, _I, C.POINTER(C.c_int), _U, C.POINTER(C.c_int)]),
     ("ArapFlow_SolverResidentLayout", _I, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("ArapFlow_ResidentFailed", _I, [_VP]),
     ("ArapFlow_SolverStamps", _I, [_VP, _VP]),

@@ -1788,6 +1788,18 @@ int ArapFlow_ResidentDeal(const int* active_tiles, unsigned nsolves, int* table,
         }
     return sets;
 }
+int ArapFlow_ResidentTiles(const uint8_t* mask_red, unsigned W, unsigned H, int aligned, int* origins, unsigned cap,
+                           int* bandx0)
+{
+    if (!mask_red || W == 0 || H == 0) return -1;
+    std::vector<int> tiles, bx;
+    build_resident_tiles(mask_red, (int)W, (int)H, aligned != 0, tiles, bx, nullptr);
+    if (origins)
+        for (size_t i = 0; i < tiles.size() && i < cap; ++i) origins[i] = tiles[i];
+    if (bandx0)
+        for (size_t i = 0; i < bx.size(); ++i) bandx0[i] = bx[i];
+    return (int)tiles.size();
+}
 int ArapFlow_SolverResidentLayout(ArapFlow_Solver* s, int* launches_per_step, int* solves_in_flight)
 {
     if (!s) return -1;

@@ -222,6 +222,12 @@ int ArapFlow_SolverLaunchesFor(ArapFlow_Solver* s, unsigned nframes);
  * `table_launches` launches the 512 workgroup entries {solve or -1, rank in its group, group size, granule offset}
  * (int[table_launches][512][4]).  -1 on bad arguments. */
 int ArapFlow_ResidentDeal(const int* active_tiles, unsigned nsolves, int* table, unsigned table_launches);
+/* The resident kernel's work list of one solve, as a pure host function (no device needed): 32x8 tiles in bands of 8
+ * rows; inside a band the tiles start at the band's first active vertex (`aligned` != 0; else at x = 0) and follow each
+ * other every 32 columns; tiles without an active vertex (mask_red == 0) are left out.  Writes up to `cap` tile origins
+ * (x0 + W * y0, band by band) and the ceil(H / 8) band start columns; returns the number of tiles, -1 on bad arguments. */
+int ArapFlow_ResidentTiles(const uint8_t* mask_red, unsigned W, unsigned H, int aligned, int* origins, unsigned cap,
+                           int* bandx0);
 /* The drop-in path (Opt_ProblemInit/Step/Solve) takes the resident kernel too when the caller's UrShape is the
  * pixel grid on every active vertex (what the application passes, CombinedSolver.h:207-221) and the active tiles
  * fit.  Mask and UrShape are looked at before EVERY step (the reference re-reads its parameters at every step and

@@ -201,3 +201,47 @@ int main(void)
                            "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "no state" in r.stdout, r.stdout + r.stderr
+
+
+def test_resident_tile_lists_cover_every_active_vertex_once():
+    """ArapFlow_ResidentTiles (pure host function): the aligned 32x8 tiling the resident kernel works on.  Every active
+    vertex lies in exactly one listed tile, no listed tile is empty, tiles of a band start at the band's first active
+    column and do not overlap, and the aligned form never needs more tiles than the fixed grid."""
+    from arap_flow_amd import build, synth
+    lib = ctypes.CDLL(build.build())
+    lib.ArapFlow_ResidentTiles.restype = ctypes.c_int
+    rng = np.random.default_rng(3)
+    cases = [synth.make_frame(854, 480, seed=s)["mask_red"] for s in range(3)]
+    cases += [synth.segment_masks(synth.make_frame(300, 200, seed=5, K=3))[1]["mask_red"], np.zeros((37, 70), np.uint8),
+              np.full((20, 50), 255, np.uint8), np.where(rng.random((61, 131)) < 0.3, 0, 255).astype(np.uint8)]
+    for m in cases:
+        m = np.ascontiguousarray(m)
+        H, W = m.shape
+        counts = {}
+        for aligned in (1, 0):
+            cap = ((W + 31) // 32 + 1) * ((H + 7) // 8)
+            org = np.zeros(cap, np.int32)
+            bx = np.zeros((H + 7) // 8, np.int32)
+            n = lib.ArapFlow_ResidentTiles(m.ctypes.data_as(ctypes.c_void_p), W, H, aligned, org.ctypes.data_as(ctypes.c_void_p),
+                                           cap, bx.ctypes.data_as(ctypes.c_void_p))
+            assert 0 <= n <= cap
+            counts[aligned] = n
+            cover = np.zeros((H, W), np.int32)
+            prev = {}
+            for o in org[:n]:
+                y0, x0 = divmod(int(o), W)
+                assert y0 % 8 == 0 and (x0 - bx[y0 // 8]) % 32 == 0 and x0 >= bx[y0 // 8]
+                if not aligned:
+                    assert x0 % 32 == 0
+                assert prev.get(y0, -32) + 32 <= x0                                  # ascending, no overlap inside a band
+                prev[y0] = x0
+                blk = m[y0:y0 + 8, x0:x0 + 32]
+                assert (blk == 0).any()                                              # no empty tile
+                cover[y0:y0 + 8, x0:x0 + 32] += 1
+            assert np.all(cover[m == 0] == 1)                                        # every active vertex exactly once
+            if aligned:
+                for b in range((H + 7) // 8):
+                    cols = np.nonzero((m[8 * b:8 * b + 8] == 0).any(0))[0]
+                    if len(cols):
+                        assert bx[b] == cols[0]
+        assert counts[1] <= counts[0]
