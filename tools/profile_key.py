@@ -4,17 +4,26 @@ import glob
 import hashlib
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _code_only(text):
+    """C++ source without comments and without whitespace: what the compiler sees, so that editing a comment does not
+    orphan the measured records"""
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\s+", "", text)
+
+
 def source_hash():
-    """sha256 over the HIP sources of libarapopt.so (file names + contents), first 16 hex digits"""
+    """sha256 over the code (comments and whitespace stripped) of the HIP sources of libarapopt.so, first 16 hex digits"""
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "arap_flow_amd", "csrc", "*"))):
         if f.endswith((".h", ".hip")):
             h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
+            h.update(_code_only(open(f, "r", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
