@@ -16,12 +16,16 @@
 //     (b) the preconditioned residual z of tile-border vertices, from which each workgroup rebuilds
 //     its halo of p = z + beta p locally, so there are exactly TWO group-wide waits per iteration,
 //     the two the algorithm cannot avoid.
-// Inter-workgroup visibility follows cdna_hip_programming.md Guideline 16 (R1/R2): handed-off bytes
-// are written with agent-scope (sc1, write-through) stores, every storing wave drains vmcnt(0), the
-// workgroup barriers, ONE lane publishes {tag, value} granules, consumers poll them with sc1 loads
-// and read the payload with sc1 loads only.  Correctness never depends on placement; dealing a group
-// workgroups of equal blockIdx & 7 merely tends to keep it on one XCD.  Every spin is bounded; a timeout
-// sets an error word and the host redoes the step on the two-kernel path.
+// Inter-workgroup visibility: everything one workgroup hands to another travels as DATA-TAGGED granules,
+// {tag << 32 | 32 payload bits} written with one 8-byte store (agent scope, write-through; plain when the
+// readers provably share the writer's L2) and read with sc1 loads that bypass the reader's L1: a reader
+// that sees the tag of the iteration it is in has that iteration's payload -- no flag after the data, no
+// "my stores have landed" wait on the writer's side, no ordering assumed between two stores.  The partial
+// sums are polled (group_sum*); the border z is written by waves 1-3 while wave 0 runs the sum, read after
+// the sum and its tags checked (they all but always match: the sum took longer than a store travels).
+// Correctness never depends on placement; dealing a group workgroups of equal blockIdx & 7 merely tends to
+// keep it on one XCD.  Every spin is bounded; a timeout sets an error word and the host redoes the step on
+// the two-kernel path.
 //
 // Arithmetic: the same float32 operation list as k_pcg_a / k_pcg_b (and the CPU oracle), for the
 // pixel-grid UrShape the frame solver always uses (CombinedSolver.h:207-221): d_s = U(c)-U(n) = -s.
@@ -44,6 +48,7 @@ constexpr int RES_TILES_PER_WG = RES_SLOTS;
 // 7 tile slots per workgroup instead of 8-9, the phases are proportional to the slots) and the halo cells per tile
 // from 136 to 80.
 constexpr int RT_X = 32, RT_Y = 8;
+constexpr int RES_ZX = 2 * RT_X + 2 * RT_Y;      // published z entries per tile (its border)
 static_assert(RT_X * RT_Y == RES_THREADS && RT_Y == 2 * (RES_THREADS / 64), "one vertex per lane, two rows per wavefront");
 constexpr int RES_MAX_HALO = RES_TILES_PER_WG * (2 * RT_X + 2 * RT_Y);          // 80 halo cells per tile
 constexpr int RES_HALO_PER_THREAD = (RES_MAX_HALO + RES_THREADS - 1) / RES_THREADS;   // 3
@@ -54,16 +59,17 @@ constexpr int LPLANE = LROW * LROWS;     // 340 floats
 constexpr int LTILE = 5 * LPLANE;        // float2 (px,py) plane | float2 (cos,sin) plane | float pa plane
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
                               + ((RES_MAX_HALO * 8 + 15) / 16) * 16   // halo list (u16), then the decoded halo table (uint2)
-                              + RES_TILES_PER_WG * 8 + 8 + 384; // tile origins, tables, scratch  (67.4 KB: 2 per CU)
+                              + RES_TILES_PER_WG * 8 + 8 + 384  // tile origins, tables, scratch
+                              + RES_TILES_PER_WG * 3 * RES_ZX * 4;   // border z on its way out  (75.9 KB: 2 per CU)
 static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two workgroups per CU");
 #ifndef RES_HALO_REG_SLOTS
 #define RES_HALO_REG_SLOTS 8  // keep the decoded halo entries in registers when at most this many tile slots are in use
 #endif
 #ifndef RES_WREG_SLOTS
-#define RES_WREG_SLOTS 6      // keep the five per-vertex edge / fit weights in registers when at most this many slots are in use
+#define RES_WREG_SLOTS 7      // keep the per-vertex edge weights in registers when at most this many slots are in use
 #endif
 #ifndef RES_WREG_FIT
-#define RES_WREG_FIT 1        // ... the fit weight too (0: only the four edge weights)
+#define RES_WREG_FIT 6        // ... the fit weight too when at most this many slots are in use (else only the four edge weights)
 #endif
 #ifndef RES_OWN_LOCAL
 #define RES_OWN_LOCAL 1       // a group wait takes the workgroup's own partial from its register, not from its granules
@@ -102,6 +108,10 @@ struct ResDev {
     const int* ntiles;          // [batch]
     const int* tilepos;         // [batch][rtX * rtY] position in the list of the k-th tile column of a band, -1 = inactive
     const int* bandx0;          // [batch][rtY] x of the first tile of every 8-row band
+    // z of the tile-BORDER vertices, what a neighbouring tile's halo needs: per tile of a solve's list three planes
+    // (z_x, z_y, z_alpha) of RES_ZX entries {top row 0..31 | bottom row 32..63 | left column 64..71 | right column
+    // 72..79} (the four corners twice), every entry a granule {tag << 32 | float bits} like those of the group sums
+    unsigned long long* zx;     // [batch][RES_MAX_TILES][3][RES_ZX]
     int rtX, rtY;               // ceil(W / 32) tile columns at most per band, ceil(H / 8) bands
     unsigned long long* gran;   // [RES_GRAN_PER_LAUNCH]  {tag << 32 | 32 value bits}
     unsigned* err;              // [1] 0 = ok
@@ -117,26 +127,22 @@ struct ResDev {
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 
-__device__ __forceinline__ void st_sc1_f2(float2* p, float2 v)
+// entry of tile-local vertex (x, y) in its tile's border export, -1 for an interior vertex
+__device__ __forceinline__ int border_entry(int x, int y)
 {
-    unsigned long long u = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
-    __hip_atomic_store((unsigned long long*)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return y == 0 ? x : (y == RT_Y - 1 ? RT_X + x : (x == 0 ? 2 * RT_X + y : (x == RT_X - 1 ? 2 * RT_X + RT_Y + y : -1)));
 }
-__device__ __forceinline__ void st_sc1_f(float* p, float v)
+// One published z component: {tag, bits} in a single 8-byte store, so a reader that sees the tag of the iteration it
+// is in also sees that iteration's value.
+// Same-XCD fast path (`fast`): when every reader of a workgroup's granules reports the same XCC id (checked at run
+// time, see the kernel), the XCD's L2 is the coherence point for all of them, so they may be written with workgroup-
+// scope stores (they stay in that L2 instead of being written through to memory) and are still read with sc1 loads
+// (which bypass the reader's L1 and are served by that same L2).
+__device__ __forceinline__ void st_tagged(unsigned long long* p, unsigned tag, float v, bool fast)
 {
-    __hip_atomic_store((unsigned*)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Same-XCD fast path: when every workgroup of a group reports the same XCC id (checked at run time, see
-// the kernel), the XCD's L2 is the coherence point for all of them, so handed-off bytes may be written with
-// plain stores (they stay in that L2 instead of being written through to memory) and are still read with
-// sc1 loads (which bypass the reader's L1 and are served by that same L2).
-__device__ __forceinline__ void st_pub_f2(float2* p, float2 v, bool fast)
-{
-    if (fast) *p = v; else st_sc1_f2(p, v);
-}
-__device__ __forceinline__ void st_pub_f(float* p, float v, bool fast)
-{
-    if (fast) *p = v; else st_sc1_f(p, v);
+    const unsigned long long g = ((unsigned long long)tag << 32) | __float_as_uint(v);
+    if (fast) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 // (a.x*b.x + c.x, a.y*b.y + c.y) with one rounding each: v_pk_fma_f32
@@ -152,16 +158,6 @@ __device__ __forceinline__ float keep_if(unsigned f, float v)
     int m;      // (as asm: the compiler would turn sext(bit) & v back into v_and + v_cmp + v_cndmask)
     asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(f), "n"(BITNO));
     return __uint_as_float(__float_as_uint(v) & (unsigned)m);
-}
-__device__ __forceinline__ float2 ld_sc1_f2(const float2* p)
-{
-    const unsigned long long u =
-        __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-}
-__device__ __forceinline__ float ld_sc1_f(const float* p)
-{
-    return __uint_as_float(__hip_atomic_load((const unsigned*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // Group-wide sum of one double per workgroup.  `part` is this workgroup's partial (valid in wave 0,
@@ -239,9 +235,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
 //      `subfast`, checked at run time like `fast`) -> every workgroup of the run knows its run's sum S_sub;
 //   2. the first workgroup of every run publishes S_sub write-through; every workgroup polls those nsub (<= 8)
 //      granules and adds them in run order -> the same bits everywhere, deterministic.
-// z visibility is transitive: a workgroup's z stores have landed before its level-1 granule, a run's leader writes
-// the level-2 granule only after it has seen every level-1 granule of its run, and a consumer reads z only after it
-// has seen every level-2 granule.
+// (The border z does not depend on these sums for its visibility: its granules carry their own tags.)
 __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigned long long* gran_group,
                                             unsigned long long* gran2 /* [2][8][16] of this group */, int rank, int wgs,
                                             float* bcast, unsigned* err, float& out, bool subfast)
@@ -320,8 +314,6 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
 // other runs' from the second.  Lane k adds ranks k, k + 64, ... in rank order, then the fixed DPP tree: the same bits
 // in every workgroup.  The fabric carries (nsub - 1) x 64 granule pairs per poller and sweep: fine for 2 runs (128
 // pollers x 1 KB), too much for 4 or 8 (round 1 measured 3.4 us for a flat gather over 256 workgroups).
-// z visibility: a workgroup's z stores (write-through where a reader sits on another XCD) are drained before either copy
-// of its granule is stored.
 __device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigned long long* gran_group,
                                             unsigned long long* granx_group, int rank, int wgs, float* bcast, unsigned* err,
                                             float& out, bool subfast)
@@ -377,13 +369,9 @@ __device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigne
 }
 
 // block-wide sum of a double over the 4 wavefronts; result valid in wave 0 lane 0
-template <bool DRAIN = false>
 __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 doubles */)
 {
     v = wave_sum_l63(v);
-    // DRAIN: the wave's earlier global stores must have landed before the workgroup barrier below (R1); waiting
-    // here, after the lane sum, hides part of the store latency
-    if (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 63) wsum[wave] = v;
     __syncthreads();
@@ -408,7 +396,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 {
     static_assert(NS >= 1 && NS <= RES_SLOTS, "slots");
     unsigned long long tA = 0, tS1 = 0, tB = 0, tS2 = 0, tU = 0, t0 = 0, t1 = 0;
-    unsigned long long tm[4] = {0, 0, 0, 0}, tbs = 0;     // STAMPS: inside the group sums (shader clocks; wave 0)
+    unsigned long long tm[4] = {0, 0, 0, 0}, tbs = 0, tzr = 0;     // STAMPS: inside the group sums (shader clocks; wave 0)
 #define RES_STAMP(acc) do { if (STAMPS) { t1 = __builtin_amdgcn_s_memrealtime(); acc += t1 - t0; t0 = t1; } } while (0)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Group of this workgroup: dealt by the host (ResWg).  Speed only (never correctness): workgroups are dealt
@@ -438,6 +426,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     double* wsum = (double*)(bcast + 6);                                  // 4 doubles (+ 1 at wsum[8])
     unsigned* nbits = (unsigned*)(wsum + 10);                             // [16] bitmap: ranks owning my halo vertices
     unsigned* nremote = nbits + 16;                                       // [1] some of them sit on another XCD
+    float* zst = (float*)((char*)lds + RES_LDS_BYTES - RES_TILES_PER_WG * 3 * RES_ZX * 4);     // [9][3][RES_ZX] border z, staged
     unsigned long long* gran_group = rd.gran + me.gran;
     unsigned long long* granx_group = rd.gran + RES_GRAN_X + me.gran;
 
@@ -550,7 +539,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         if (WREG) {
             we[j][0] = keep_if<0>(f, wr2); we[j][1] = keep_if<1>(f, wr2); we[j][2] = keep_if<2>(f, wr2);
             we[j][3] = keep_if<3>(f, wr2);
-            if (RES_WREG_FIT) we[j][4] = keep_if<4>(f, wf2);
+            if (NS <= RES_WREG_FIT) we[j][4] = keep_if<4>(f, wf2);
         }
         if (ly == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lx + 1);
         if (ly == RT_Y - 1 && (f & F_E2)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (RT_Y + 1) * LROW + lx + 1);
@@ -579,7 +568,6 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const int row = rem / LROW, col = rem - row * LROW;
                 const int2 tb = tbase[k];
                 const int gx = tb.x + col - 1, gy = tb.y + row - 1;
-                e[u].x = (unsigned)(gx + W * gy);
                 e[u].y = (unsigned)(k * (LTILE / 2) + rem) | ((unsigned)(k * LTILE + 4 * LPLANE + rem) << 16);
                 // which workgroup of the group owns that vertex (the even deal above)?  -> neighbour bitmap
                 // the tile that holds (gx, gy): band gy / 8, column (gx - first x of that band) / 32 (the halo vertex is
@@ -590,6 +578,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const int nfull = textra * (tbase_n + 1);
                 const int owner = pos < nfull ? pos / (tbase_n + 1) : textra + (pos - nfull) / (tbase_n > 0 ? tbase_n : 1);
                 if (pos >= 0 && owner != rank) atomicOr(&nbits[(owner >> 5) & 15], 1u << (owner & 31));
+                // where the owner publishes that vertex's z: its tile's border entry (my top halo row is the neighbour's
+                // bottom row, my left halo column its right column, ...)
+                const int kxc = kx < 0 ? 0 : (kx < rd.rtX ? kx : rd.rtX - 1);
+                const int lxo = gx - (rd.bandx0[(size_t)b * rd.rtY + band] + kxc * RT_X), lyo = gy - band * RT_Y;
+                const int zpos = border_entry(lxo, lyo);
+                (void)row; (void)col;
+                e[u].x = (unsigned)((pos < 0 ? 0 : pos) * (3 * RES_ZX) + zpos);
             }
         }
         __syncthreads();                             // every u16 entry has been read
@@ -614,9 +609,15 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             asm volatile("" : "+v"(offA[n]));
         }
     }
-    float2* const zO_b = pd.zO + gb;                   // this frame's published z (uniform bases)
-    float* const zA_b = pd.zA + gb;
+    unsigned long long* const zx_b = rd.zx + (size_t)b * RES_MAX_TILES * (3 * RES_ZX);    // this solve's published border z
+    const int zent = border_entry(lx, ly);             // this lane's entry in its tile's border export
     bool alive = true;
+    // No granule of this workgroup's tiles may carry a tag from an earlier launch: tag 0 everywhere (write-through,
+    // whatever the placement), landed before this workgroup's epoch-1 granule below -- which every reader waits for.
+    for (int c = tid; c < tp * (3 * RES_ZX); c += RES_THREADS)
+        __hip_atomic_store(zx_b + (size_t)tfirst * (3 * RES_ZX) + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------
     // every workgroup publishes xcc + 65536 xcc^2 through the placement-independent protocol (epoch 1);
     // the ids are all equal iff  wgs * sum(xcc^2) == (sum xcc)^2.
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 RES_EDGE(3, 3,      ci,  si,    cn,  sn,   -ci, -si)      // s=( 0,-1): q=(-ci,-si) h=(-cn,-sn)
 #undef RES_EDGE
                 {
-                    const float wf = (WREG && RES_WREG_FIT) ? we[WREG ? j : 0][4] : keep_if<4>(f, wf2);
+                    const float wf = (WREG && NS <= RES_WREG_FIT) ? we[WREG ? j : 0][4] : keep_if<4>(f, wf2);
                     axy = fma2(make_float2(wf, wf), pv, axy);
                 }
                 const float ax = axy.x, ay = axy.y;
@@ -789,29 +790,27 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         float alpha = 0.f;
         if (sigma > 0.f) alpha = rho / sigma;
         acc = 0.0;
-        // (the store flavour is a compile-time constant inside the loop: as a run-time flag it costs six scalar
-        //  branches per slot)
-        auto phase_b = [&](auto fast_c) {
-            constexpr bool FAST = decltype(fast_c)::value;
+        const unsigned ztag = 2u * l + 3u;                 // (the epoch of the sum that follows: unique in the launch, never 0)
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                    unsigned f = fl[j];
-                asm volatile("" : "+v"(f));
-                const float mo = mo_[j], ma = ma_[j];
-                rx[j] = fmaf(-alpha, apx[j], rx[j]);
-                ry[j] = fmaf(-alpha, apy[j], ry[j]);
-                ra[j] = fmaf(-alpha, apa[j], ra[j]);
-                const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-                if (f & F_ACT) {
-                    const unsigned i = (unsigned)(ibase[j] + loff);
-                    st_pub_f2((float2*)((char*)zO_b + (size_t)(i * 8u)), make_float2(zx, zy), FAST);   // (publishing border
-                    st_pub_f((float*)((char*)zA_b + (size_t)(i * 4u)), za, FAST);   // vertices only: slower, divergent stores)
-                }
-                acc += (double)keep_if<5>(f, dot3(zx, zy, za, rx[j], ry[j], ra[j]));
-                __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NS; ++j) {
+            unsigned f = fl[j];
+            asm volatile("" : "+v"(f));
+            const float mo = mo_[j], ma = ma_[j];
+            rx[j] = fmaf(-alpha, apx[j], rx[j]);
+            ry[j] = fmaf(-alpha, apy[j], ry[j]);
+            ra[j] = fmaf(-alpha, apa[j], ra[j]);
+            const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
+            // Only a tile's border is ever read by another tile (rows 0 and 7, the two end columns): those lanes drop
+            // their z into the LDS staging area; waves 1-3 send it out after the block sum below.  (Vector memory stores
+            // cost their issue slot whatever the number of active lanes: from here they would be 21 nearly empty store
+            // instructions per wave, from the staging area 9 full ones.)
+            if (zent >= 0) {
+                float* q_ = zst + j * (3 * RES_ZX) + zent;
+                q_[0] = zx; q_[RES_ZX] = zy; q_[2 * RES_ZX] = za;
             }
-        };
-        if (zfast) phase_b(std::true_type{}); else phase_b(std::false_type{});
+            acc += (double)keep_if<5>(f, dot3(zx, zy, za, rx[j], ry[j], ra[j]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // delta += alpha p while the z stores travel (own p from LDS, reads one slot ahead)
         {
             float2 Dp[2];
@@ -835,11 +834,21 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
         float rhoNew;
         RES_STAMP(tB);
-        // (every storing wave drains inside block_sum8, before the workgroup barrier: R1)
         {
             const unsigned long long cb = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
-            const double bs = block_sum8<true>(acc, wsum);
+            const double bs = block_sum8(acc, wsum);
             if (STAMPS) tbs += __builtin_amdgcn_s_memtime() - cb;
+            // (past the barrier of the block sum: the staged border z is complete.)  Waves 1-3 publish it, every
+            // component a {tag, bits} granule, while wave 0 is busy with the group sum; nothing waits for these stores --
+            // the reader checks the tags (update phase below), and they have a whole group sum to travel.
+            if (wave != 0) {
+                unsigned long long* const out = zx_b + (size_t)tfirst * (3 * RES_ZX);
+                if (zfast) {
+                    for (int g = tid - 64; g < tp * (3 * RES_ZX); g += RES_THREADS - 64) st_tagged(out + g, ztag, zst[g], true);
+                } else {
+                    for (int g = tid - 64; g < tp * (3 * RES_ZX); g += RES_THREADS - 64) st_tagged(out + g, ztag, zst[g], false);
+                }
+            }
             alive = hierx ? group_sum_x(bs, 2u * l + 3u, gran_group, granx_group, rank, wgs, bcast, rd.err, rhoNew, subfast)
                   : hier  ? group_sum_h(bs, 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
                           : group_sum(bs, 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast, nullptr, rd.nowait != 0,
@@ -852,18 +861,17 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         rho = rhoNew;
         if (l + 1 == L) break;
         // ---------------- p = z + beta p ---------------------------------------------------------------
-        // (1) issue the sc1 loads of the neighbours' z for every halo cell of the workgroup (all in flight)
-        float2 hz2[RES_HALO_PER_THREAD];
-        float hz1[RES_HALO_PER_THREAD];
+        // (1) issue the loads of the neighbours' border z for this workgroup's halo cells (all in flight)
+        unsigned long long hg[RES_HALO_PER_THREAD][3];
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
-            hz2[u] = make_float2(0.f, 0.f);
-            hz1[u] = 0.f;
+            hg[u][0] = hg[u][1] = hg[u][2] = (unsigned long long)ztag << 32;
             if (tid + u * RES_THREADS < nh) {
                 // uniform base + 32-bit byte offset formed here (precomputed 64-bit addresses would spill)
                 const unsigned gi = HREG ? hreg[u].x : htab[tid + u * RES_THREADS].x;
-                hz2[u] = ld_sc1_f2((const float2*)((const char*)zO_b + (size_t)(gi * 8u)));
-                hz1[u] = ld_sc1_f((const float*)((const char*)zA_b + (size_t)(gi * 4u)));
+                const unsigned long long* q_ = (const unsigned long long*)((const char*)zx_b + (size_t)(gi * 8u));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) hg[u][c] = __hip_atomic_load(q_ + c * RES_ZX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // (2) own cells while those loads fly: branch free (an excluded lane computes 0 + beta * 0), LDS reads one
@@ -885,16 +893,51 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             }
 #undef RES_LOADP
         }
-        // (3) halo cells: p_halo = z_halo + beta p_halo (the owner computes the same expression)
+        // (3) halo cells: p_halo = z_halo + beta p_halo (the owner computes the same expression).  A granule whose tag is
+        //     this iteration's holds this iteration's value; the group sum in between took far longer than a store
+        //     travels, so the tags all but always match, and a lane whose granule is still the previous iteration's
+        //     reads it again.
+        {
+            bool fresh = true;
+#pragma unroll
+            for (int u = 0; u < RES_HALO_PER_THREAD; ++u)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) fresh = fresh && (unsigned)(hg[u][c] >> 32) == ztag;
+            if (!__all(fresh) && !rd.nowait) {
+                for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {
+                    if (STAMPS) tzr += 1;
+                    fresh = true;
+#pragma unroll
+                    for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
+                        if (tid + u * RES_THREADS < nh) {
+                            const unsigned gi = HREG ? hreg[u].x : htab[tid + u * RES_THREADS].x;
+                            const unsigned long long* q_ = (const unsigned long long*)((const char*)zx_b + (size_t)(gi * 8u));
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                hg[u][c] = __hip_atomic_load(q_ + c * RES_ZX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                fresh = fresh && (unsigned)(hg[u][c] >> 32) == ztag;
+                            }
+                        }
+                    }
+                    if (__all(fresh)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                // gave up: the host sees the error word and redoes the step on the two-kernel path (the launch runs on
+                // with whatever it read: its results are discarded)
+                if (!fresh) atomicExch(rd.err, 0xDEAD0000u | (ztag & 0xffffu));
+            }
+        }
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
+            const float2 hz2_ = make_float2(__uint_as_float((unsigned)hg[u][0]), __uint_as_float((unsigned)hg[u][1]));
+            const float hz1_ = __uint_as_float((unsigned)hg[u][2]);
             if (tid + u * RES_THREADS < nh) {
                 const unsigned pk = HREG ? hreg[u].y : htab[tid + u * RES_THREADS].y;
                 float2* P = (float2*)((char*)lds + (pk & 0xffffu) * 8u);
                 float* A = (float*)((char*)lds + (pk >> 16) * 4u);
                 const float2 po = *P;
-                *P = make_float2(fmaf(beta, po.x, hz2[u].x), fmaf(beta, po.y, hz2[u].y));
-                *A = fmaf(beta, *A, hz1[u]);
+                *P = make_float2(fmaf(beta, po.x, hz2_.x), fmaf(beta, po.y, hz2_.y));
+                *A = fmaf(beta, *A, hz1_);
             }
         }
         __syncthreads();
@@ -902,7 +945,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     if (STAMPS && tid == 0) {
         unsigned long long* o = rd.stamps + (size_t)blockIdx.x * 16;
-        o[8] = tbs; o[9] = tm[0]; o[10] = tm[1]; o[11] = tm[2]; o[12] = tm[3];      // block sums, publish, poll, tail (clocks); sweeps
+        o[8] = tbs; o[9] = tm[0]; o[10] = tm[1]; o[11] = tm[2]; o[12] = tm[3]; o[13] = tzr;     // block sums, publish, poll, tail (clocks); sweeps; repeated looks at the z tags (wave 0)
         o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; { unsigned pc = 0; for (int q = 0; q < 16; ++q) pc += __popc(nbits[q]); o[6] = (unsigned long long)nh | ((unsigned long long)pc << 32) | ((unsigned long long)*nremote << 48); } o[7] = (fast ? 1ull : 0ull) | (zfast ? 2ull : 0ull) | (hier ? 4ull : 0ull) | (subfast ? 8ull : 0ull);
     }
     if (!alive) return;

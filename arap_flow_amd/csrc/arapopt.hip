@@ -260,6 +260,12 @@ static void plan_enable_resident(Opt_Plan* p)
     const size_t sz_tp = align_up((size_t)p->batch * p->rd.rtX * p->rd.rtY * sizeof(int), 256);
     const size_t sz_bx = align_up((size_t)p->batch * p->rd.rtY * sizeof(int), 256);
     const size_t sz_ra = align_up((size_t)p->rd.rtX * p->rd.rtY, 256);               // drop-in analysis: tile activity
+    {
+        // border z of every tile (arap_resident.h: ResDev::zx)
+        const size_t nz = (size_t)p->batch * RES_MAX_TILES * 3 * RES_ZX * sizeof(unsigned long long);
+        HC(hipMalloc((void**)&p->rd.zx, nz));
+        HC(hipMemsetAsync(p->rd.zx, 0, nz, st->stream));
+    }
     HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp + sz_bx + sz_ra));
     HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp + sz_bx + sz_ra, st->stream));
     char* c = (char*)p->res_block;
@@ -628,6 +634,7 @@ static void plan_free(Opt_Plan* p)
     if (p->pd.red) (void)hipFree(p->pd.red);
     if (p->pd.costred) (void)hipFree(p->pd.costred);
     if (p->res_block) (void)hipFree(p->res_block);
+    if (p->rd.zx) (void)hipFree(p->rd.zx);
     if (p->rd.stamps) (void)hipFree(p->rd.stamps);
     if (p->d_notgrid) (void)hipFree(p->d_notgrid);
     if (p->d_t64list) (void)hipFree(p->d_t64list);

@@ -33,6 +33,8 @@ clk = o[used, 8:12] / (2.0 * L * 4)           # per sum; 4 launches... (the tabl
 clk = o[used, 8:12] / (2.0 * L)
 print("per group sum, shader clocks: block sum %.0f  publish %.0f  poll %.0f  tail %.0f   sweeps per sum %.2f" % (
     clk[:, 0].mean(), clk[:, 1].mean(), clk[:, 2].mean(), clk[:, 3].mean(), (o[used, 12] / (2.0 * L)).mean()))
+print("repeated looks at the neighbours' z tags per iteration (wave 0 of each workgroup): mean %.3f  max %.3f" % (
+    (o[used, 13] / float(L)).mean(), (o[used, 13] / float(L)).max()))
 # per-workgroup view of one group (the workgroups of XCD 0: blockIdx & 7 == 0), sorted by tiles then phase A time
 idx = np.arange(512)
 g0 = used & ((idx & 7) == 0)
