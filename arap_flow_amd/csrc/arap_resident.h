@@ -612,6 +612,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     unsigned long long* const zx_b = rd.zx + (size_t)b * RES_MAX_TILES * (3 * RES_ZX);    // this solve's published border z
     const int zent = border_entry(lx, ly);             // this lane's entry in its tile's border export
     bool alive = true;
+    float alpha_last = 0.f;                            // alpha of the last iteration (its delta update happens after the loop)
     // No granule of this workgroup's tiles may carry a tag from an earlier launch: tag 0 everywhere (write-through,
     // whatever the placement), landed before this workgroup's epoch-1 granule below -- which every reader waits for.
     for (int c = tid; c < tp * (3 * RES_ZX); c += RES_THREADS)
@@ -811,27 +812,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             acc += (double)keep_if<5>(f, dot3(zx, zy, za, rx[j], ry[j], ra[j]));
             __builtin_amdgcn_sched_barrier(0);
         }
-        // delta += alpha p while the z stores travel (own p from LDS, reads one slot ahead)
-        {
-            float2 Dp[2];
-            float Da[2];
-#define RES_LOADP(J, P2_, PA_)                                                                         \
-            {                                                                                          \
-                const char* T_ = (const char*)lds + (J) * (LTILE * 4);                                 \
-                P2_[(J) & 1] = *(const float2*)(T_ + offP[0]);                                         \
-                PA_[(J) & 1] = *(const float*)(T_ + offA[0] + LPLANE * 16);                            \
-            }
-            RES_LOADP(0, Dp, Da)
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                    if (j + 1 < NS) RES_LOADP(j + 1, Dp, Da)
-                __builtin_amdgcn_sched_barrier(0);
-                dx_[j] = fmaf(alpha, Dp[j & 1].x, dx_[j]);
-                dy_[j] = fmaf(alpha, Dp[j & 1].y, dy_[j]);
-                da_[j] = fmaf(alpha, Da[j & 1], da_[j]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        // (delta += alpha p is left to the update phase, which reads the workgroup's own p anyway)
         float rhoNew;
         RES_STAMP(tB);
         {
@@ -859,7 +840,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         float beta = 0.f;
         if (rho > 0.f) beta = rhoNew / rho;
         rho = rhoNew;
-        if (l + 1 == L) break;
+        if (l + 1 == L) { alpha_last = alpha; break; }
         // ---------------- p = z + beta p ---------------------------------------------------------------
         // (1) issue the loads of the neighbours' border z for this workgroup's halo cells (all in flight)
         unsigned long long hg[RES_HALO_PER_THREAD][3];
@@ -874,24 +855,30 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 for (int c = 0; c < 3; ++c) hg[u][c] = __hip_atomic_load(q_ + c * RES_ZX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        // (2) own cells while those loads fly: branch free (an excluded lane computes 0 + beta * 0), LDS reads one
-        //     slot ahead of the writes
+        // (2) own cells while those loads fly: delta += alpha p, then p = z + beta p.  Branch free (an excluded lane
+        //     computes 0 + beta * 0).  The registers of Ap are free here: every slot's own p is fetched from LDS up front
+        //     (one slot ahead, each slot paid an LDS round trip).
         {
-            float2 Up[2];
-            float Ua[2];
-            RES_LOADP(0, Up, Ua)
+            float2 Up[NS];
+            float Ua[NS];
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                    if (j + 1 < NS) RES_LOADP(j + 1, Up, Ua)
-                __builtin_amdgcn_sched_barrier(0);
+                const char* T_ = (const char*)lds + j * (LTILE * 4);
+                Up[j] = *(const float2*)(T_ + offP[0]);
+                Ua[j] = *(const float*)(T_ + offA[0] + LPLANE * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
                 char* T_ = (char*)lds + j * (LTILE * 4);
                 const float mo = mo_[j], ma = ma_[j];
                 const float zx = mo * rx[j], zy = mo * ry[j], za = ma * ra[j];
-                *(float2*)(T_ + offP[0]) = make_float2(fmaf(beta, Up[j & 1].x, zx), fmaf(beta, Up[j & 1].y, zy));
-                *(float*)(T_ + offA[0] + LPLANE * 16) = fmaf(beta, Ua[j & 1], za);
-                __builtin_amdgcn_sched_barrier(0);
+                dx_[j] = fmaf(alpha, Up[j].x, dx_[j]);
+                dy_[j] = fmaf(alpha, Up[j].y, dy_[j]);
+                da_[j] = fmaf(alpha, Ua[j], da_[j]);
+                *(float2*)(T_ + offP[0]) = make_float2(fmaf(beta, Up[j].x, zx), fmaf(beta, Up[j].y, zy));
+                *(float*)(T_ + offA[0] + LPLANE * 16) = fmaf(beta, Ua[j], za);
             }
-#undef RES_LOADP
         }
         // (3) halo cells: p_halo = z_halo + beta p_halo (the owner computes the same expression).  A granule whose tag is
         //     this iteration's holds this iteration's value; the group sum in between took far longer than a store
@@ -949,7 +936,18 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; { unsigned pc = 0; for (int q = 0; q < 16; ++q) pc += __popc(nbits[q]); o[6] = (unsigned long long)nh | ((unsigned long long)pc << 32) | ((unsigned long long)*nremote << 48); } o[7] = (fast ? 1ull : 0ull) | (zfast ? 2ull : 0ull) | (hier ? 4ull : 0ull) | (subfast ? 8ull : 0ull);
     }
     if (!alive) return;
-    // ---- epilogue: delta back to the plan images for k_gn_update --------------------------------------
+    // ---- epilogue: the last iteration's delta += alpha p, then delta back to the plan images for k_gn_update ----
+    if (L > 0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const char* T_ = (const char*)lds + j * (LTILE * 4);
+            const float2 p2 = *(const float2*)(T_ + offP[0]);
+            const float pa1 = *(const float*)(T_ + offA[0] + LPLANE * 16);
+            dx_[j] = fmaf(alpha_last, p2.x, dx_[j]);
+            dy_[j] = fmaf(alpha_last, p2.y, dy_[j]);
+            da_[j] = fmaf(alpha_last, pa1, da_[j]);
+        }
+    }
     int lo = loff;
     asm volatile("" : "+v"(lo));       // (else the nine store addresses are formed before the loop and spilled)
 #pragma unroll
