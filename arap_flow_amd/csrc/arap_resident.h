@@ -49,6 +49,8 @@ constexpr int RES_TILES_PER_WG = RES_SLOTS;
 // from 136 to 80.
 constexpr int RT_X = 32, RT_Y = 8;
 constexpr int RES_ZX = 2 * RT_X + 2 * RT_Y;      // published z entries per tile (its border)
+constexpr int RES_ZG = 2 * RES_ZX;               // ... as granules: two per entry
+constexpr int RES_MAX_L = 32000;                 // PCG iterations per launch: the z granules carry 16-bit tags (2 l + 3)
 static_assert(RT_X * RT_Y == RES_THREADS && RT_Y == 2 * (RES_THREADS / 64), "one vertex per lane, two rows per wavefront");
 constexpr int RES_MAX_HALO = RES_TILES_PER_WG * (2 * RT_X + 2 * RT_Y);          // 80 halo cells per tile
 constexpr int RES_HALO_PER_THREAD = (RES_MAX_HALO + RES_THREADS - 1) / RES_THREADS;   // 3
@@ -60,7 +62,7 @@ constexpr int LTILE = 5 * LPLANE;        // float2 (px,py) plane | float2 (cos,s
 constexpr int RES_LDS_BYTES = RES_TILES_PER_WG * LTILE * 4      // halo'd p / cos / sin tiles
                               + ((RES_MAX_HALO * 8 + 15) / 16) * 16   // halo list (u16), then the decoded halo table (uint2)
                               + RES_TILES_PER_WG * 8 + 8 + 384  // tile origins, tables, scratch
-                              + RES_TILES_PER_WG * 3 * RES_ZX * 4;   // border z on its way out  (75.9 KB: 2 per CU)
+                              + RES_TILES_PER_WG * RES_ZX * 16;      // border z on its way out  (78.9 KB: 2 per CU)
 static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two workgroups per CU");
 #ifndef RES_HALO_REG_SLOTS
 #define RES_HALO_REG_SLOTS 8  // keep the decoded halo entries in registers when at most this many tile slots are in use
@@ -108,10 +110,11 @@ struct ResDev {
     const int* ntiles;          // [batch]
     const int* tilepos;         // [batch][rtX * rtY] position in the list of the k-th tile column of a band, -1 = inactive
     const int* bandx0;          // [batch][rtY] x of the first tile of every 8-row band
-    // z of the tile-BORDER vertices, what a neighbouring tile's halo needs: per tile of a solve's list three planes
-    // (z_x, z_y, z_alpha) of RES_ZX entries {top row 0..31 | bottom row 32..63 | left column 64..71 | right column
-    // 72..79} (the four corners twice), every entry a granule {tag << 32 | float bits} like those of the group sums
-    unsigned long long* zx;     // [batch][RES_MAX_TILES][3][RES_ZX]
+    // z of the tile-BORDER vertices, what a neighbouring tile's halo needs: per tile of a solve's list RES_ZX entries
+    // {top row 0..31 | bottom row 32..63 | left column 64..71 | right column 72..79} (the four corners twice), every entry
+    // two granules like those of the group sums, but with 16-bit tags so that three floats fit:
+    //   {z_x | low half of z_y << 32 | tag << 48}, {z_alpha | high half of z_y << 32 | tag << 48}
+    unsigned long long* zx;     // [batch][RES_MAX_TILES][RES_ZX][2]
     int rtX, rtY;               // ceil(W / 32) tile columns at most per band, ceil(H / 8) bands
     unsigned long long* gran;   // [RES_GRAN_PER_LAUNCH]  {tag << 32 | 32 value bits}
     unsigned* err;              // [1] 0 = ok
@@ -132,15 +135,15 @@ __device__ __forceinline__ int border_entry(int x, int y)
 {
     return y == 0 ? x : (y == RT_Y - 1 ? RT_X + x : (x == 0 ? 2 * RT_X + y : (x == RT_X - 1 ? 2 * RT_X + RT_Y + y : -1)));
 }
-// One published z component: {tag, bits} in a single 8-byte store, so a reader that sees the tag of the iteration it
-// is in also sees that iteration's value.
+// One published granule: {tag, payload} in a single 8-byte store, so a reader that sees the tag of the iteration it
+// is in also sees that iteration's payload.
 // Same-XCD fast path (`fast`): when every reader of a workgroup's granules reports the same XCC id (checked at run
 // time, see the kernel), the XCD's L2 is the coherence point for all of them, so they may be written with workgroup-
 // scope stores (they stay in that L2 instead of being written through to memory) and are still read with sc1 loads
 // (which bypass the reader's L1 and are served by that same L2).
-__device__ __forceinline__ void st_tagged(unsigned long long* p, unsigned tag, float v, bool fast)
+__device__ __forceinline__ void st_tagged(unsigned long long* p, unsigned hi /* tag << 16 | 16 payload bits */, float v, bool fast)
 {
-    const unsigned long long g = ((unsigned long long)tag << 32) | __float_as_uint(v);
+    const unsigned long long g = ((unsigned long long)hi << 32) | __float_as_uint(v);
     if (fast) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     double* wsum = (double*)(bcast + 6);                                  // 4 doubles (+ 1 at wsum[8])
     unsigned* nbits = (unsigned*)(wsum + 10);                             // [16] bitmap: ranks owning my halo vertices
     unsigned* nremote = nbits + 16;                                       // [1] some of them sit on another XCD
-    float* zst = (float*)((char*)lds + RES_LDS_BYTES - RES_TILES_PER_WG * 3 * RES_ZX * 4);     // [9][3][RES_ZX] border z, staged
+    float4* zst = (float4*)((char*)lds + RES_LDS_BYTES - RES_TILES_PER_WG * RES_ZX * 16);     // [9][RES_ZX] border z, staged: (z_x, z_y, z_alpha, z_y)
     unsigned long long* gran_group = rd.gran + me.gran;
     unsigned long long* granx_group = rd.gran + RES_GRAN_X + me.gran;
 
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                 const int lxo = gx - (rd.bandx0[(size_t)b * rd.rtY + band] + kxc * RT_X), lyo = gy - band * RT_Y;
                 const int zpos = border_entry(lxo, lyo);
                 (void)row; (void)col;
-                e[u].x = (unsigned)((pos < 0 ? 0 : pos) * (3 * RES_ZX) + zpos);
+                e[u].x = (unsigned)((pos < 0 ? 0 : pos) * RES_ZG + 2 * zpos);
             }
         }
         __syncthreads();                             // every u16 entry has been read
@@ -609,14 +612,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             asm volatile("" : "+v"(offA[n]));
         }
     }
-    unsigned long long* const zx_b = rd.zx + (size_t)b * RES_MAX_TILES * (3 * RES_ZX);    // this solve's published border z
+    unsigned long long* const zx_b = rd.zx + (size_t)b * RES_MAX_TILES * RES_ZG;    // this solve's published border z
     const int zent = border_entry(lx, ly);             // this lane's entry in its tile's border export
     bool alive = true;
     float alpha_last = 0.f;                            // alpha of the last iteration (its delta update happens after the loop)
     // No granule of this workgroup's tiles may carry a tag from an earlier launch: tag 0 everywhere (write-through,
     // whatever the placement), landed before this workgroup's epoch-1 granule below -- which every reader waits for.
-    for (int c = tid; c < tp * (3 * RES_ZX); c += RES_THREADS)
-        __hip_atomic_store(zx_b + (size_t)tfirst * (3 * RES_ZX) + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = tid; c < tp * RES_ZG; c += RES_THREADS)
+        __hip_atomic_store(zx_b + (size_t)tfirst * RES_ZG + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------
@@ -820,8 +823,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             // cost their issue slot whatever the number of active lanes: from here they would be 21 nearly empty store
             // instructions per wave, from the staging area 9 full ones.)
             if (zent >= 0) {
-                float* q_ = zst + j * (3 * RES_ZX) + zent;
-                q_[0] = zx; q_[RES_ZX] = zy; q_[2 * RES_ZX] = za;
+                zst[j * RES_ZX + zent] = make_float4(zx, zy, za, zy);
             }
             acc += (double)keep_if<5>(f, dot3(zx, zy, za, rx[j], ry[j], ra[j]));
             __builtin_amdgcn_sched_barrier(0);
@@ -838,11 +840,22 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             // component a {tag, bits} granule, while wave 0 is busy with the group sum; nothing waits for these stores --
             // the reader checks the tags (update phase below), and they have a whole group sum to travel.
             if (wave != 0) {
-                unsigned long long* const out = zx_b + (size_t)tfirst * (3 * RES_ZX);
+                // granule g of the export = half g & 1 of staged entry g >> 1: (z_x, z_y) -> {z_x, low half of z_y},
+                // (z_alpha, z_y) -> {z_alpha, high half of z_y}; a thread's granules all have its parity (the stride is even)
+                unsigned long long* const out = zx_b + (size_t)tfirst * RES_ZG;
+                const float2* const st2 = (const float2*)zst;
+                const unsigned sh = (tid & 1) ? 16u : 0u;
+                static_assert(((RES_THREADS - 64) & 1) == 0, "a thread keeps the parity of its granules");
                 if (zfast) {
-                    for (int g = tid - 64; g < tp * (3 * RES_ZX); g += RES_THREADS - 64) st_tagged(out + g, ztag, zst[g], true);
+                    for (int g = tid - 64; g < tp * RES_ZG; g += RES_THREADS - 64) {
+                        const float2 v = st2[g];
+                        st_tagged(out + g, (ztag << 16) | ((__float_as_uint(v.y) >> sh) & 0xffffu), v.x, true);
+                    }
                 } else {
-                    for (int g = tid - 64; g < tp * (3 * RES_ZX); g += RES_THREADS - 64) st_tagged(out + g, ztag, zst[g], false);
+                    for (int g = tid - 64; g < tp * RES_ZG; g += RES_THREADS - 64) {
+                        const float2 v = st2[g];
+                        st_tagged(out + g, (ztag << 16) | ((__float_as_uint(v.y) >> sh) & 0xffffu), v.x, false);
+                    }
                 }
             }
             alive = hierx ? group_sum_x(bs, 2u * l + 3u, gran_group, granx_group, rank, wgs, bcast, rd.err, rhoNew, subfast)
@@ -858,16 +871,16 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         if (l + 1 == L) { alpha_last = alpha; break; }
         // ---------------- p = z + beta p ---------------------------------------------------------------
         // (1) issue the loads of the neighbours' border z for this workgroup's halo cells (all in flight)
-        unsigned long long hg[RES_HALO_PER_THREAD][3];
+        unsigned long long hg[RES_HALO_PER_THREAD][2];
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
-            hg[u][0] = hg[u][1] = hg[u][2] = (unsigned long long)ztag << 32;
+            hg[u][0] = hg[u][1] = (unsigned long long)ztag << 48;
             if (tid + u * RES_THREADS < nh) {
                 // uniform base + 32-bit byte offset formed here (precomputed 64-bit addresses would spill)
                 const unsigned gi = HREG ? hreg[u].x : htab[tid + u * RES_THREADS].x;
                 const unsigned long long* q_ = (const unsigned long long*)((const char*)zx_b + (size_t)(gi * 8u));
 #pragma unroll
-                for (int c = 0; c < 3; ++c) hg[u][c] = __hip_atomic_load(q_ + c * RES_ZX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int c = 0; c < 2; ++c) hg[u][c] = __hip_atomic_load(q_ + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // (2) own cells while those loads fly: delta += alpha p, then p = z + beta p.  Branch free (an excluded lane
@@ -905,7 +918,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #pragma unroll
             for (int u = 0; u < RES_HALO_PER_THREAD; ++u)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) fresh = fresh && (unsigned)(hg[u][c] >> 32) == ztag;
+                for (int c = 0; c < 2; ++c) fresh = fresh && (unsigned)(hg[u][c] >> 48) == ztag;
             if (!__all(fresh) && !rd.nowait) {
                 for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {
                     if (STAMPS) tzr += 1;
@@ -916,9 +929,9 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                             const unsigned gi = HREG ? hreg[u].x : htab[tid + u * RES_THREADS].x;
                             const unsigned long long* q_ = (const unsigned long long*)((const char*)zx_b + (size_t)(gi * 8u));
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                hg[u][c] = __hip_atomic_load(q_ + c * RES_ZX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                fresh = fresh && (unsigned)(hg[u][c] >> 32) == ztag;
+                            for (int c = 0; c < 2; ++c) {
+                                hg[u][c] = __hip_atomic_load(q_ + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                fresh = fresh && (unsigned)(hg[u][c] >> 48) == ztag;
                             }
                         }
                     }
@@ -932,8 +945,9 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
 #pragma unroll
         for (int u = 0; u < RES_HALO_PER_THREAD; ++u) {
-            const float2 hz2_ = make_float2(__uint_as_float((unsigned)hg[u][0]), __uint_as_float((unsigned)hg[u][1]));
-            const float hz1_ = __uint_as_float((unsigned)hg[u][2]);
+            const float2 hz2_ = make_float2(__uint_as_float((unsigned)hg[u][0]),
+                                            __uint_as_float(((unsigned)(hg[u][0] >> 32) & 0xffffu) | ((unsigned)(hg[u][1] >> 32) << 16)));
+            const float hz1_ = __uint_as_float((unsigned)hg[u][1]);
             if (tid + u * RES_THREADS < nh) {
                 const unsigned pk = HREG ? hreg[u].y : htab[tid + u * RES_THREADS].y;
                 float2* P = (float2*)((char*)lds + (pk & 0xffffu) * 8u);

@@ -262,7 +262,7 @@ static void plan_enable_resident(Opt_Plan* p)
     const size_t sz_ra = align_up((size_t)p->rd.rtX * p->rd.rtY, 256);               // drop-in analysis: tile activity
     {
         // border z of every tile (arap_resident.h: ResDev::zx)
-        const size_t nz = (size_t)p->batch * RES_MAX_TILES * 3 * RES_ZX * sizeof(unsigned long long);
+        const size_t nz = (size_t)p->batch * RES_MAX_TILES * RES_ZG * sizeof(unsigned long long);
         HC(hipMalloc((void**)&p->rd.zx, nz));
         HC(hipMemsetAsync(p->rd.zx, 0, nz, st->stream));
     }
@@ -418,6 +418,7 @@ static bool plan_resident_eligible(const Opt_Plan* p)
 {
     if (!p->res_capable || !p->st->use_resident) return false;
     if (p->st->res_cooldown > 0) return false;          // pausing after a timed-out launch (plan_resident_failed)
+    if (p->sp.lIterations > RES_MAX_L) return false;    // (the border-z granules carry 16-bit iteration tags)
     if (!p->res_frames) {
         // drop-in plan: only with the images analysed just before this step (plan_analyse_for_resident)
         const Slot& a = p->opt_res_slot;

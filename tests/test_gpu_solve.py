@@ -195,6 +195,31 @@ def test_resident_and_two_kernel_paths_are_bit_identical(gpu_state):
             assert a["cost"] == b["cost"]
 
 
+def test_resident_kernel_longest_pcg_loop_and_the_limit_above_it(gpu_state):
+    """The border-z granules of the resident kernel carry 16-bit iteration tags (2 l + 3): launches of up to
+    RES_MAX_L = 32 000 PCG iterations run on it (tags up to 64 003, bit-identical to the two-kernel path); one
+    iteration more and the solve takes the two-kernel path (arapopt.hip: plan_resident_eligible)."""
+    from arap_flow_amd import synth
+    W, H = 96, 64
+    frames = [synth.make_frame(W, H, seed=40 + s, K=1, fd=2) for s in range(3)]
+    outs = {}
+    for L, resident in ((32000, True), (32000, False), (32001, True)):
+        gpu_state.set_resident(resident)
+        fs = opt.FrameSolver(gpu_state, W, H, batch=len(frames))
+        for b, f in enumerate(frames):
+            fs.set_frame(b, f["mask_red"], f["constraints"])
+        fs.solve(len(frames), 1, 1, L)
+        outs[(L, resident)] = [fs.results(b, want_rgb=False) for b in range(len(frames))]
+        assert (fs.stats()["resident_launches"] > 0) == (resident and L <= 32000), (L, resident)
+        assert gpu_state.lib.ArapFlow_ResidentFailed(gpu_state.handle) == 0        # no wait gave up (no stale tag)
+        fs.close()
+    gpu_state.set_resident(True)
+    # (a PCG loop this far past convergence may end in non-finite values: the comparison is on the bit patterns)
+    bits = lambda r: (r["offset"].view(np.uint32), r["angle"].view(np.uint32))
+    for a, b in zip(outs[(32000, True)], outs[(32000, False)]):
+        assert all(np.array_equal(x, y) for x, y in zip(bits(a), bits(b)))
+
+
 @pytest.mark.parametrize("case", ["synth160x96", "cat512"])
 def test_T3_full_schedule_deterministic_twin(gpu_state, oracle, golden_dir, case):
     """Tier T3: the full 19/8/400 schedule, HIP vs the float32 CPU oracle that performs the same operation
