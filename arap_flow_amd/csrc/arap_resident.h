@@ -73,6 +73,20 @@ static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two wor
 #ifndef RES_WREG_FIT
 #define RES_WREG_FIT 6        // ... the fit weight too when at most this many slots are in use (else only the four edge weights)
 #endif
+// A workgroup's first look at the group's granules comes this long (x 64 clocks) after it has published its own: the
+// others publish at about the same time and a store needs ~300 clocks to become visible, so a look taken at once finds
+// nothing and costs a full L2 round trip before the next one (2.54 -> 2.14 sweeps per sum, 4.62 -> 4.54 us per iteration)
+#ifndef RES_FIRST_LOOK
+#define RES_FIRST_LOOK 5
+#endif
+#ifndef RES_FIRST_LOOK_2
+#define RES_FIRST_LOOK_2 14     // second level of a two-level sum: the leaders' granules travel through the fabric
+                                // (854x480 mask == 0: 0 / 8 / 12 / 16 / 20 / 24 / 32 -> 4.88 / 4.94 / 4.99 / 4.97 / 4.85 / 4.73 / 4.46 frames/s)
+#endif
+#ifndef RES_FIRST_LOOK_X
+#define RES_FIRST_LOOK_X 20     // one-hop sum of a group of two XCD runs
+                                // (1920x1080 --multseg: 0 / 5 / 12 / 16 / 20 / 24 / 28 -> 3.85 / 3.90 / 3.96 / 4.11 / 4.14 / 4.13 / 3.98 frames/s)
+#endif
 #ifndef RES_OWN_LOCAL
 #define RES_OWN_LOCAL 1       // a group wait takes the workgroup's own partial from its register, not from its granules
 #endif
@@ -194,6 +208,7 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
         double v = 0.0;
         bool ok = false;
         if (tm) { c1 = __builtin_amdgcn_s_memtime(); tm[0] += c1 - c0; c0 = c1; }
+        __builtin_amdgcn_s_sleep(RES_FIRST_LOOK);
         for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {
             if (tm) tm[3] += 1;
             v = 0.0;
@@ -261,6 +276,7 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
         }
         double v = 0.0;
         bool ok = false;
+        __builtin_amdgcn_s_sleep(RES_FIRST_LOOK);
         for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {           // level 1: lane k <-> workgroup k of the run
             const unsigned long long lo = __hip_atomic_load(buf + RES_GS * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long hi = __hip_atomic_load(buf + RES_GS * lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -281,6 +297,7 @@ __device__ __forceinline__ bool group_sum_h(double part, unsigned epoch, unsigne
         bool ok2 = false;
         v = 0.0;
         if (ok) {
+            __builtin_amdgcn_s_sleep(RES_FIRST_LOOK_2);
             for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {       // level 2: lane k <-> run k
                 bool mine_ok = true;
                 v = 0.0;
@@ -344,6 +361,7 @@ __device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigne
         }
         double v = 0.0;
         bool ok = false;
+        __builtin_amdgcn_s_sleep(RES_FIRST_LOOK_X);
         for (unsigned spins = 0; spins < RES_SPIN_LIMIT; ++spins) {
             v = 0.0;
             bool mine_ok = true;
