@@ -70,6 +70,12 @@ static_assert(2 * ((RES_LDS_BYTES + 1279) / 1280 * 1280) <= 160 * 1024, "two wor
 #ifndef RES_WREG_SLOTS
 #define RES_WREG_SLOTS 7      // keep the per-vertex edge weights in registers when at most this many slots are in use
 #endif
+#ifndef RES_WREG_8
+#define RES_WREG_8 2          // edge weights (of four) kept in registers at 8 slots (3 spill; 2: +1.5 %)
+#endif
+#ifndef RES_WREG_9
+#define RES_WREG_9 2          // ... at 9 slots
+#endif
 #ifndef RES_WREG_FIT
 #define RES_WREG_FIT 6        // ... the fit weight too when at most this many slots are in use (else only the four edge weights)
 #endif
@@ -490,7 +496,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     // phase A weights an edge by wr^2 or +0 (fit term: wf^2 or +0) according to the vertex's flag bits.  With registers
     // to spare (NS <= RES_WREG_SLOTS) the five weights per slot are formed once, here; otherwise from the flags in
     // every iteration (two bit operations each: 10 of the 51 VALU instructions of a vertex)
-    constexpr bool WREG = NS <= RES_WREG_SLOTS;
+    constexpr int NWR = NS <= RES_WREG_SLOTS ? 4 : (NS == 8 ? RES_WREG_8 : RES_WREG_9);     // edge weights kept per slot
+    constexpr bool WREG = NWR > 0;
     float we[WREG ? NS : 1][5];
     const int loff = lx + W * ly;                      // this lane's vertex inside a tile: index = ibase + loff
 
@@ -558,8 +565,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         const unsigned f = fl[j];
         mo_[j] = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)];      // M^-1 of the Offset components
         if (WREG) {
-            we[j][0] = keep_if<0>(f, wr2); we[j][1] = keep_if<1>(f, wr2); we[j][2] = keep_if<2>(f, wr2);
-            we[j][3] = keep_if<3>(f, wr2);
+            if (NWR > 0) we[j][0] = keep_if<0>(f, wr2);
+            if (NWR > 1) we[j][1] = keep_if<1>(f, wr2);
+            if (NWR > 2) we[j][2] = keep_if<2>(f, wr2);
+            if (NWR > 3) we[j][3] = keep_if<3>(f, wr2);
             if (NS <= RES_WREG_FIT) we[j][4] = keep_if<4>(f, wf2);
         }
         if (ly == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lx + 1);
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                     const float2 qO = LqO[sj][E], cn2 = Lcn[sj][E];                                    \
                     const float qA = LqA[sj][E];                                                       \
                     const float cn = cn2.x, sn = cn2.y;                                                \
-                    const float w = WREG ? we[WREG ? j : 0][BITNO] : keep_if<BITNO>(f, wr2);           \
+                    const float w = (BITNO < NWR) ? we[WREG ? j : 0][BITNO] : keep_if<BITNO>(f, wr2);  \
                     const float2 e = pv - qO;                                                          \
                     const float2 t = fma2(make_float2(NQX, NQY), pa2, e);                              \
                     const float2 u = fma2(make_float2(NHX, NHY), make_float2(qA, qA), e + t);          \
