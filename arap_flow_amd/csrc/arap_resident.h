@@ -413,8 +413,10 @@ __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 do
 // grid = 512 workgroups (groups x wgs), block = 256, dynamic LDS = RES_LDS_BYTES (two workgroups per CU)
 //
 // LDS map: 9 halo'd tiles x {px,py,pa,cos,sin} (61 200 B); halo table (uint2 per halo cell, <= 720; it
-// starts life as the u16 cell list); tile origins int2[9]; the 10-entry M^-1_O table; broadcast + reduction scratch.
-// Registers per lane: r(3) delta(3) Ap(3) M^-1_A M^-1_O flags for each of the 9 slots = 108 of 242.
+// starts life as the u16 cell list); tile origins int2[9]; the 10-entry M^-1_O table; broadcast + reduction scratch;
+// the staging area of the border z (9 x 80 float4, 11 520 B).
+// Registers per lane: r(3) delta(3) Ap(3) M^-1_A M^-1_O flags per slot (12 x NS), plus the edge weights where they fit
+// (4 per slot up to 7 slots, 2 at 8 and 9): 253 VGPRs at 7 slots, 249 at 9, no scratch.
 // NS = tile slots the loops run over (1 .. RES_SLOTS): the most tiles any workgroup of the LAUNCH holds (the host picks
 // the instantiation per launch, arapopt.hip: launch_resident).  The phases are fully unrolled and branch free over the
 // slots, so their length is proportional to NS: a launch whose solves need 7 tiles per workgroup runs the 7-slot kernel.

@@ -25,7 +25,7 @@ print("frames", B, "wall us/iter (4 GN steps incl. launches):", dt / (4 * L) * 1
 fl = out[:, 7][used]
 print("of", int(used.sum()), "workgroups:", int((fl & 1).astype(bool).sum()), "in a group on one XCD,", int((fl & 4).astype(bool).sum()), "in a group with two-level sums,", int((fl & 2).astype(bool).sum()), "keep their z in L2 (plain stores)")
 print("workgroups active", used.sum(), "tiles/WG", o[used, 5].min(), o[used, 5].max(), "halo cells", (out[:, 6][used] & 0xffffffff).min(), (out[:, 6][used] & 0xffffffff).max())
-for n, col in zip(["phaseA", "wait1", "phaseB+drain", "wait2", "update"], us.T):
+for n, col in zip(["phaseA", "wait1", "phaseB", "wait2", "update"], us.T):
     print("%-14s mean %.2f  min %.2f  max %.2f us" % (n, col.mean(), col.min(), col.max()))
 print("sum of means %.2f us" % us.mean(0).sum())
 # inside the two group sums of an iteration (wave 0, shader clocks -> us at the clock the launch ran at, from the stamps)
