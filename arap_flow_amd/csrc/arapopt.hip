@@ -149,6 +149,7 @@ struct Opt_Plan {
     int res_tiles_all = 0;          // 32x8 tiles of the whole grid (share of active tiles: plan_active_tiles_majority)
     bool hole_pending = false;      // test hook ARAPOPT_FORCE_RES_FAIL=2: the next table upload leaves one workgroup out
     ResWg* d_wgmap = nullptr;       // [batch][RES_WGS]: one table per resident launch of a GN step
+    ResWg* pin_wgmap = nullptr;     // pinned staging of the same size
     std::vector<ResWg> h_wgmap;     // what d_wgmap holds
     int res_sets = 0;               // resident launches per GN step
     std::vector<int> res_ns;        // per launch: tile slots in use = most tiles any of its workgroups holds
@@ -266,6 +267,7 @@ static void plan_enable_resident(Opt_Plan* p)
         HC(hipMalloc((void**)&p->rd.zx, nz));
         HC(hipMemsetAsync(p->rd.zx, 0, nz, st->stream));
     }
+    HC(hipHostMalloc((void**)&p->pin_wgmap, sz_map, hipHostMallocDefault));
     HC(hipMalloc(&p->res_block, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp + sz_bx + sz_ra));
     HC(hipMemsetAsync(p->res_block, 0, sz_gr + sz_tl + sz_nt + 256 + sz_map + sz_tp + sz_bx + sz_ra, st->stream));
     char* c = (char*)p->res_block;
@@ -636,6 +638,7 @@ static void plan_free(Opt_Plan* p)
     if (p->pd.costred) (void)hipFree(p->pd.costred);
     if (p->res_block) (void)hipFree(p->res_block);
     if (p->rd.zx) (void)hipFree(p->rd.zx);
+    if (p->pin_wgmap) (void)hipHostFree(p->pin_wgmap);
     if (p->rd.stamps) (void)hipFree(p->rd.stamps);
     if (p->d_notgrid) (void)hipFree(p->d_notgrid);
     if (p->d_t64list) (void)hipFree(p->d_t64list);
@@ -830,7 +833,11 @@ static void plan_gn_step(Opt_Plan* p)
             HC(hipMemcpy(p->d_wgmap, holed.data(), holed.size() * sizeof(ResWg), hipMemcpyHostToDevice));
             p->hole_pending = false;
         } else {
-            HC(hipMemcpyAsync(p->d_wgmap, p->h_wgmap.data(), p->h_wgmap.size() * sizeof(ResWg), hipMemcpyHostToDevice,
+            // (from pinned staging: a pageable source makes the call wait until the stream has drained -- i.e. for the
+            //  other solver object's whole solve.  The staging buffer is rewritten only by this plan's next deal, which
+            //  comes after this solve has been waited for.)
+            memcpy(p->pin_wgmap, p->h_wgmap.data(), p->h_wgmap.size() * sizeof(ResWg));
+            HC(hipMemcpyAsync(p->d_wgmap, p->pin_wgmap, p->h_wgmap.size() * sizeof(ResWg), hipMemcpyHostToDevice,
                               st->stream));
         }
         plan_drop_graph(p);
@@ -1432,6 +1439,8 @@ struct ArapFlow_Solver {
     std::vector<FrameDev> hfr;
     FrameDev* dfr = nullptr;
     WarpJob* djobs = nullptr;
+    WarpJob* pin_jobs = nullptr;     // pinned staging of the warp jobs of one solve call
+    unsigned* pin_err = nullptr;     // the resident kernel's error word as of the end of the last solve call (pinned)
     std::vector<uint8_t> has_rgb;
     std::vector<uint64_t> nactive;
     uint64_t last_pcg = 0, last_active = 0, last_grid = 0;
@@ -1455,7 +1464,8 @@ struct ArapFlow_Solver {
 static void solver_enqueue_warp(ArapFlow_Solver* s, unsigned nframes)
 {
     Opt_State* st = s->st;
-    std::vector<WarpJob> jobs(nframes);
+    if (!s->pin_jobs) HC(hipHostMalloc((void**)&s->pin_jobs, sizeof(WarpJob) * s->batch, hipHostMallocDefault));
+    WarpJob* jobs = s->pin_jobs;             // (pinned: see plan_gn_step on pageable sources)
     for (unsigned b = 0; b < nframes; ++b) {
         const FrameDev& f = s->hfr[b];
         WarpJob& j = jobs[b];
@@ -1465,7 +1475,7 @@ static void solver_enqueue_warp(ArapFlow_Solver* s, unsigned nframes)
         j.out_rgb = s->has_rgb[b] ? f.out_rgb : nullptr;
         j.out_mask = f.out_mask;
     }
-    HC(hipMemcpyAsync(s->djobs, jobs.data(), sizeof(WarpJob) * nframes, hipMemcpyHostToDevice, st->stream));
+    HC(hipMemcpyAsync(s->djobs, jobs, sizeof(WarpJob) * nframes, hipMemcpyHostToDevice, st->stream));
     const dim3 g((s->W + 63) / 64, (s->H + 3) / 4, nframes);
     hipLaunchKernelGGL(k_warp_raster, g, dim3(64, 4), 0, st->stream, s->djobs, s->W, s->H);
     hipLaunchKernelGGL(k_warp_resolve, dim3((s->N + 255) / 256, 1, nframes), dim3(256), 0, st->stream, s->djobs,
@@ -1498,6 +1508,11 @@ static void solver_enqueue(ArapFlow_Solver* s)
         while (plan_step(p) != 0) {}
     }
     if (s->a_warp) solver_enqueue_warp(s, nframes);
+    if (p->res_capable) {
+        if (!s->pin_err) HC(hipHostMalloc((void**)&s->pin_err, 64, hipHostMallocDefault));
+        *s->pin_err = 0u;
+        HC(hipMemcpyAsync(s->pin_err, p->rd.err, sizeof(unsigned), hipMemcpyDeviceToHost, st->stream));
+    }
     HC(hipEventRecord(s->ev_done, st->stream));
     if (s->a_download) {
         if (!s->pin_out) {
@@ -1593,6 +1608,8 @@ void ArapFlow_SolverFree(ArapFlow_Solver* s)
     (void)hipEventDestroy(s->ev_up); (void)hipEventDestroy(s->ev_done); (void)hipEventDestroy(s->ev_dl);
     if (s->pin_in) (void)hipHostFree(s->pin_in);
     if (s->pin_out) (void)hipHostFree(s->pin_out);
+    if (s->pin_jobs) (void)hipHostFree(s->pin_jobs);
+    if (s->pin_err) (void)hipHostFree(s->pin_err);
     (void)hipFree(s->block);
     delete s;
 }
@@ -1695,7 +1712,10 @@ int ArapFlow_SolverWait(ArapFlow_Solver* s)
     // The resident path needs all its workgroups co-resident; if a launch gave up (GPU shared with another process) the
     // device skipped every later update: redo the whole schedule once, now on the two-kernel path (plan_resident_failed
     // pauses the resident path), from the reset.
-    if (p->res_launches > 0 && plan_resident_failed(p)) {
+    // (The error word came back with the solve, in stream order, into pinned memory: reading it through the compute
+    //  stream here would wait for whatever ANOTHER solver object has enqueued there since -- with two alternating solver
+    //  objects, for the other one's whole solve.  Only a non-zero word takes the blocking path.)
+    if (p->res_launches > 0 && s->pin_err && *s->pin_err != 0u && plan_resident_failed(p)) {
         HC(hipStreamSynchronize(s->copy));
         solver_enqueue(s);
         s->retried = true;
