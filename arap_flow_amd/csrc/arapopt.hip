@@ -652,8 +652,10 @@ static void plan_free(Opt_Plan* p)
 static void plan_reserve(Opt_Plan* p, int lIterations, int ncost)
 {
     Opt_State* st = p->st;
+    // (the stream is drained only where a buffer that earlier launches may still use is replaced: a first allocation
+    //  must not wait for another solver object's running solve)
     if (lIterations > p->lcap || !p->pd.red) {
-        HC(hipStreamSynchronize(st->stream));
+        if (p->pd.red) HC(hipStreamSynchronize(st->stream));
         plan_drop_graph(p);
         if (p->pd.red) HC(hipFree(p->pd.red));
         p->lcap = lIterations < 16 ? 16 : lIterations;
@@ -661,7 +663,7 @@ static void plan_reserve(Opt_Plan* p, int lIterations, int ncost)
         HC(hipMalloc(&p->pd.red, (size_t)p->batch * p->pd.nslots * NSHARD * sizeof(double)));
     }
     if (ncost > p->ccap || !p->pd.costred) {
-        HC(hipStreamSynchronize(st->stream));
+        if (p->pd.costred) HC(hipStreamSynchronize(st->stream));
         plan_drop_graph(p);
         if (p->pd.costred) HC(hipFree(p->pd.costred));
         p->ccap = ncost < 16 ? 16 : ncost;
@@ -1464,7 +1466,6 @@ struct ArapFlow_Solver {
 static void solver_enqueue_warp(ArapFlow_Solver* s, unsigned nframes)
 {
     Opt_State* st = s->st;
-    if (!s->pin_jobs) HC(hipHostMalloc((void**)&s->pin_jobs, sizeof(WarpJob) * s->batch, hipHostMallocDefault));
     WarpJob* jobs = s->pin_jobs;             // (pinned: see plan_gn_step on pageable sources)
     for (unsigned b = 0; b < nframes; ++b) {
         const FrameDev& f = s->hfr[b];
@@ -1509,7 +1510,6 @@ static void solver_enqueue(ArapFlow_Solver* s)
     }
     if (s->a_warp) solver_enqueue_warp(s, nframes);
     if (p->res_capable) {
-        if (!s->pin_err) HC(hipHostMalloc((void**)&s->pin_err, 64, hipHostMallocDefault));
         *s->pin_err = 0u;
         HC(hipMemcpyAsync(s->pin_err, p->rd.err, sizeof(unsigned), hipMemcpyDeviceToHost, st->stream));
     }
@@ -1586,6 +1586,13 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
     HC(hipEventCreateWithFlags(&s->ev_dl, hipEventDisableTiming));
     s->pin_in_slot = align_up(12 * N, 256);
     HC(hipHostMalloc((void**)&s->pin_in, s->pin_in_slot * batch, hipHostMallocDefault));
+    // (allocated here, not at first use: hipHostMalloc waits for the device, i.e. for another solver object's running solve)
+    HC(hipHostMalloc((void**)&s->pin_jobs, sizeof(WarpJob) * batch, hipHostMallocDefault));
+    HC(hipHostMalloc((void**)&s->pin_err, 64, hipHostMallocDefault));
+    if (st->own_stream) {           // the asynchronous use (ArapFlow_UseOwnStream first): downloads will be asked for
+        s->pin_out_slot = align_up(12 * (size_t)s->N, 256);
+        HC(hipHostMalloc((void**)&s->pin_out, s->pin_out_slot * batch, hipHostMallocDefault));
+    }
     s->has_rgb.assign(batch, 0);
     s->nactive.assign(batch, 0);
     const float wfit = sqrtf(100.0f), wreg = sqrtf(0.01f);   // CombinedSolver.h:173-177
