@@ -223,6 +223,38 @@ def test_resident_kernel_without_the_xcd_fast_paths(tmp_path):
     assert r.returncode == 0 and "write-through ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+def test_two_solver_objects_do_not_wait_for_each_other(tmp_path):
+    """The persistent worker alternates two solver objects on one state (own compute stream): while one solves, the other
+    is filled, enqueued and, later, waited for.  Neither enqueueing B nor waiting for A may wait for the other object's
+    solve (they did, through synchronisations of the shared stream: the worker then ran strictly serially, 298 instead of
+    286 ms per batch).  Own process: ArapFlow_UseOwnStream changes the state."""
+    code = (
+        "import sys, time, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from arap_flow_amd import opt, synth\n"
+        "st = opt.State(); st.use_own_stream()\n"
+        "W, H = 854, 480\n"
+        "lanes = [opt.FrameSolver(st, W, H, batch=8) for _ in range(2)]\n"
+        "fr = [synth.make_frame(W, H, seed=s) for s in range(32)]\n"
+        "worst = []\n"
+        "for rnd in range(2):\n"
+        "    for k in range(2):\n"
+        "        for b in range(8):\n"
+        "            f = fr[16 * rnd + 8 * k + b]; lanes[k].set_frame(b, f['mask_red'], f['constraints'], rgb=f['rgb'])\n"
+        "    t0 = time.perf_counter(); lanes[0].solve_async(8, 4, 8, 400)\n"
+        "    t1 = time.perf_counter(); lanes[1].solve_async(8, 4, 8, 400)\n"
+        "    t2 = time.perf_counter(); lanes[0].wait()\n"
+        "    t3 = time.perf_counter(); lanes[1].wait()\n"
+        "    t4 = time.perf_counter()\n"
+        "    total = t4 - t0\n"
+        "    print('enqueue A %%.1f  enqueue B %%.1f  wait A %%.1f  wait B %%.1f ms' %% tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3)))\n"
+        "    assert (t2 - t1) < 0.25 * total, 'enqueueing B waited for A'\n"
+        "    assert (t3 - t2) < 0.70 * total and (t4 - t3) > 0.30 * total, 'waiting for A waited for B as well'\n"
+        "    assert st.lib.ArapFlow_ResidentFailed(st.handle) == 0\n"
+        "print('overlap ok')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "overlap ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_resident_failure_falls_back_to_two_kernel_path(tmp_path):
     """ARAPOPT_FORCE_RES_FAIL=1 makes every resident launch report a timed-out group wait (what happens when the GPU
     is shared and the 512 workgroups are not co-resident).  The frame solver and the drop-in path must notice, redo the
