@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- ARAP solve+warp throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either the driver launches the N ranks (python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...)
+or, when no launcher environment is present, bench.py starts them itself as fresh child processes before it touches
+torch or HIP and relays rank 0's line; a WORLD_SIZE that differs from --gpus is refused (exit 2).
 
 A "step" = one pass of the hot path over one batch of synthetic frames on every rank: the full
 arap_deform schedule (19 ramp steps x 8 Gauss-Newton steps x 400 PCG iterations,
@@ -132,11 +136,79 @@ def cpu_baseline(spec, schedule):
     return out, (h if ns == numIter else None)
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed.run environment: start the N ranks as FRESH child
+    processes (this process has not touched HIP or torch yet and never will), let rank 0's JSON line through on the
+    inherited stdout, and return the launcher's exit code.  One process per GPU, as para_gen.py --gpu 0 .. N-1 does
+    (/root/reference/para_gen.py:441-445,560-567,190)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL on this pool: dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _stub_main(a, rank, world):
+    """ARAP_BENCH_STUB=1 (tests, no GPU): the launcher, the rendezvous, the barrier-bracketed timing, the max over ranks
+    and the one JSON line of rank 0 with a sleep in place of the solve.  Nothing here is a measurement."""
+    import torch
+    import torch.distributed as dist
+    from arap_flow_amd import shard
+    if world > 1:
+        dist.init_process_group(os.environ.get("ARAP_BENCH_BACKEND", "gloo"))
+    B = a.batch if a.batch > 0 else 8
+    seeds = shard.shard_indices(world * B, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        time.sleep(0.001)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.01 * (rank + 1))
+    barrier()
+    dt = shard.max_over_ranks(time.perf_counter() - t0, dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"metric": "ARAP solve+warp frames/sec at 854x480 mesh", "value": world * B * a.steps / dt,
+                          "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "STUB (ARAP_BENCH_STUB=1: launcher test, no solve)",
+                          "config": {"workload": "stub", "frames_per_gpu_per_step": B, "frames_of_rank0": len(seeds)},
+                          "world_size_seen": dist.get_world_size() if world > 1 else 1, "gpus_flag": a.gpus}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    # --gpus N is the contract's way to ask for N ranks.  Before torch or HIP is touched: without a
+    # torch.distributed.run environment start the ranks ourselves; with one, refuse a mismatch (a line that says
+    # n_gpus = WORLD_SIZE while the caller asked for another N would be a scaling point that measures something else).
+    if a.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            sys.exit(launch_ranks(a))
+    elif int(os.environ["WORLD_SIZE"]) != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: launch with --nproc-per-node %d (or drop the "
+                         "launcher: bench.py starts its own ranks)\n" % (a.gpus, os.environ["WORLD_SIZE"], a.gpus))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ARAP_BENCH_STUB") == "1":
+        return _stub_main(a, rank, world)
     import torch
     # one process per GPU.  (ARAP_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks:
     # the ranks then share the visible GPUs and only the timing barrier / max-over-ranks change transport.)
@@ -252,7 +324,7 @@ def main():
         "hip_event_ms_per_step_rank0": ev_ms / a.steps,
         # multi-GPU bookkeeping: every rank's own time per step (its frames only, before the closing barrier) and the
         # world size torch.distributed (RCCL) reported -- the scaling curve is computed by the driver from `value`
-        "per_rank_ms_per_step": per_rank_ms, "world_size_seen": seen_world, "backend": backend if world > 1 else None,
+        "per_rank_ms_per_step": per_rank_ms, "world_size_seen": seen_world, "gpus_flag": a.gpus, "backend": backend if world > 1 else None,
         "profile_signature": sig,
     }
 

@@ -170,7 +170,7 @@ def test_bench_contract_json_line(tmp_path):
     for k in ("hbm_frac_by_counters", "valu_issue_frac", "wait_frac"):     # null unless a matching profiles/ record exists
         assert k in r, k
     assert d["parity_check"]["bit_equal"] is True                          # the timed work is the verified work
-    assert d["per_rank_ms_per_step"] and d["world_size_seen"] == 1
+    assert d["per_rank_ms_per_step"] and d["world_size_seen"] == 1 and d["gpus_flag"] == 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -197,7 +197,25 @@ def test_bench_two_ranks_under_torch_distributed_run(tmp_path):
     assert d["config"]["frames_per_gpu_per_step"] == 2
     assert abs(d["value"] - 2 * 2 * 1 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]      # all ranks' frames / max time
     assert "roofline" in d and "cpu_baseline" not in d
-    assert len(d["per_rank_ms_per_step"]) == 2 and d["world_size_seen"] == 2
+    assert len(d["per_rank_ms_per_step"]) == 2 and d["world_size_seen"] == 2 and d["gpus_flag"] == 2
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver types it for N = 1, with N = 2 and no torch.distributed.run around it:
+    bench.py starts the two ranks itself (fresh child processes, before torch / HIP is touched).  Rehearsed on one GPU
+    (gloo for the timing barrier; the ranks share the card)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ARAP_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, osp.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2",
+                        "--size", "214", "120", "--schedule", "2", "2", "30", "--no-kernel-timing"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["gpus_flag"] == 2 and d["value"] > 0
+    assert len(d["per_rank_ms_per_step"]) == 2
 
 
 def test_resident_kernel_without_the_xcd_fast_paths(tmp_path):

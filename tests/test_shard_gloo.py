@@ -65,3 +65,34 @@ def test_shard_indices_edge_cases():
     import pytest
     with pytest.raises(ValueError):
         shard.shard_indices(4, 4, 4)
+
+
+def test_bench_gpus_flag_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts two fresh ranks itself (before it touches torch or
+    HIP) and relays rank 0's line.  ARAP_BENCH_STUB=1 replaces the solve by a sleep, so this runs without a GPU; what is
+    under test is the launcher, the rendezvous on 127.0.0.1, the barrier-bracketed timing and the max over ranks."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ARAP_BENCH_STUB="1", ARAP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["gpus_flag"] == 2 and d["steps"] == 3
+    # rank 1 sleeps 20 ms per step, rank 0 10 ms: the job time is the slowest rank's
+    assert d["ms_per_step"] >= 19.0
+    assert abs(d["value"] - 2 * 8 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus(tmp_path):
+    """a launcher environment with another world size than --gpus would print a line whose n_gpus is not what was asked
+    for: refused with exit code 2 before anything is imported"""
+    env = dict(os.environ, ARAP_BENCH_STUB="1", WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=60)          # default --gpus 1 under a 2-rank launcher
+    assert r.returncode == 2
