@@ -24,7 +24,7 @@ enum : unsigned { F_E0 = 1u, F_E1 = 2u, F_E2 = 4u, F_E3 = 8u, F_FIT = 16u, F_ACT
 
 constexpr int TILE_X = 64;   // one wavefront = 64 consecutive x of one row: 256-B coalesced rows
 constexpr int TILE_Y = 4;    // 4 wavefronts per workgroup
-constexpr int NSHARD = 32;   // reduction shards per scalar (atomic contention)
+constexpr int NSHARD = 32;   // reduction groups (shards) per scalar: each shard is the order-fixed sum of one group of workgroups
 
 // One frame ("slot") of a batch: the five problem images of arap_plan.t:2-6 and the two weights.
 // Lives in device memory; the kernels index it with blockIdx.z.
@@ -68,6 +68,10 @@ struct PlanDev {
     // list launches of the per-step kernels (arap_kernels.h: vidx): every frame's active 64x4 tiles; NULL = whole grid
     const int* t64list;      // [batch][tilesX * tilesY]
     const int* t64n;         // [batch]
+    // order-fixed reductions of the kernel-per-phase paths (block_reduce_fixed below)
+    unsigned long long* part; // [batch][maxblk][4] every workgroup's partial(s) of the running launch, as tagged granules
+    unsigned* tick;           // [batch][NSHARD][2] per reduction group: {arrivals of the running launch, launches so far}
+    int maxblk;               // workgroups per frame any launch of this plan may have
 };
 
 // ---- cos/sin: same operation list as oracle/arap_oracle.c:arap_sincos_spec ----------------------
@@ -128,8 +132,8 @@ __device__ __forceinline__ float dot3(float ax, float ay, float aa, float bx, fl
 __device__ __forceinline__ int noff(int s, int W) { return s == 0 ? 1 : (s == 1 ? -1 : (s == 2 ? W : -W)); }
 
 // ---- reductions -------------------------------------------------------------------------------
-// wave64 DPP tree on doubles, then one value per wavefront combined through LDS, then ONE
-// float64 atomic per workgroup into shard (workgroup index % NSHARD) of the target scalar.
+// wave64 DPP tree on doubles, then one value per wavefront combined through LDS, then the order-fixed
+// two-level sum over the launch's workgroups (block_reduce_fixed below).
 // Sum of a double over the 64 lanes with DPP row shifts / broadcasts (the order LLVM's wave scan uses on gfx9:
 // row_shr 1, 2, 4, 8 inside each row of 16, then row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2-3).
 // The total is valid in LANE 63.  A __shfl tree costs six dependent ds_bpermute round trips (~0.3 us) per sum; the
@@ -161,41 +165,85 @@ __device__ __forceinline__ double wave_sum(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
-// all threads of the workgroup must call; blockDim = TILE_X*TILE_Y
-__device__ __forceinline__ void block_reduce_atomic(double v, double* target_shards, unsigned wg_linear)
+// ---- order-fixed reduction of one (or two) doubles over all workgroups of a launch ------------------------------
+// The reference adds per-warp partials with red.global.add.f32 in arrival order (solverGPUGaussNewton.t:312-317): its
+// sums differ from run to run.  Here a launch's sum does not depend on the order in which workgroups finish:
+//   1. inside a workgroup: the fixed DPP tree per wavefront, then the wavefronts' sums added in wave order;
+//   2. the workgroups of a frame form NSHARD groups (linear index mod NSHARD).  Every workgroup drops its partial into
+//      its own slot of `part` and takes a ticket from its group's arrival counter; the group's LAST arriver reads all
+//      the group's partials, adds them in index order (lane k: members k, k + 64, ...; then the DPP tree) and STORES the
+//      result into shard g of the target scalar -- no value is ever accumulated by an atomic;
+//   3. the consumer (read_scalar, the next kernel) adds the NSHARD shards with the same fixed tree.
+// Hand-off inside the launch: a partial travels as two data-tagged granules {tag << 32 | 32 value bits}, each one 8-byte
+// write-through store, tag = number of launches this group has seen + 1; nothing orders the stores before the ticket --
+// the last arriver checks the tags and looks again at a granule that has not landed yet (bounded; a timeout writes NaN,
+// which no caller can overlook).  Every workgroup of the launch must call this exactly once per frame it belongs to --
+// also those with nothing to add (v = 0) -- with lb = its linear index among the frame's nlb workgroups.
+__device__ __forceinline__ unsigned red_tag(const PlanDev& pd, int b, unsigned lb)
 {
-    __shared__ double wsum[TILE_Y];
-    v = wave_sum(v);
-    const unsigned lane = threadIdx.x, wave = threadIdx.y;   // block = (64, TILE_Y)
-    if (lane == 0) wsum[wave] = v;
-    __syncthreads();
-    if (wave == 0 && lane == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < TILE_Y; ++w) t += wsum[w];
-        if (t != 0.0)   // adding an exact zero changes nothing: skip the memory-side atomic
-            __hip_atomic_fetch_add(target_shards + (wg_linear % NSHARD), t, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // (may be read any time before the workgroup's own arrival: only the group's last arriver changes it)
+    return __hip_atomic_load(pd.tick + ((size_t)b * NSHARD + (lb % NSHARD)) * 2 + 1, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT) + 1u;
 }
 
-// two values at once (the LM kernels reduce a dot product and the q term together)
-__device__ __forceinline__ void block_reduce_atomic2(double v, double w, double* target_v, double* target_w,
-                                                     unsigned wg_linear)
+template <int NV>
+__device__ __forceinline__ void block_reduce_fixed(const PlanDev& pd, int b, unsigned lb, unsigned nlb, double v0,
+                                                   double v1, double* tgt0, double* tgt1, unsigned tag = 0u)
 {
-    __shared__ double wsum2[2][TILE_Y];
-    v = wave_sum(v);
-    w = wave_sum(w);
-    const unsigned lane = threadIdx.x, wave = threadIdx.y;
-    if (lane == 0) { wsum2[0][wave] = v; wsum2[1][wave] = w; }
+    __shared__ double wsumF[2][16];
+    const unsigned lin = threadIdx.y * blockDim.x + threadIdx.x, wave = lin >> 6, lane = lin & 63;
+    const unsigned nw = (blockDim.x * blockDim.y + 63u) >> 6;
+    if (tag == 0u && wave == 0) tag = red_tag(pd, b, lb);
+    v0 = wave_sum(v0);
+    if (NV > 1) v1 = wave_sum(v1);
+    if (lane == 0) { wsumF[0][wave] = v0; if (NV > 1) wsumF[1][wave] = v1; }
     __syncthreads();
-    if (wave == 0 && lane < 2) {
-        double t = 0.0;
+    if (wave != 0) return;
+    double t0 = 0.0, t1 = 0.0;
+    for (unsigned w = 0; w < nw; ++w) { t0 += wsumF[0][w]; if (NV > 1) t1 += wsumF[1][w]; }
+    const unsigned g = lb % NSHARD, ng = (nlb - g + NSHARD - 1) / NSHARD;      // members of this group: g, g + NSHARD, ...
+    unsigned* tk = pd.tick + ((size_t)b * NSHARD + g) * 2;
+    unsigned long long* const base = pd.part + (size_t)b * pd.maxblk * 4;
+    if (lane < 2u * NV) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(lane < 2 ? t0 : t1);
+        const unsigned hw = (lane & 1u) ? (unsigned)(bits >> 32) : (unsigned)bits;
+        __hip_atomic_store(base + (size_t)lb * 4 + lane, ((unsigned long long)tag << 32) | hw, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    unsigned ticket = 0u;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket + 1u != ng) return;
+    // ---- the group's last arriver ----
+    double a0 = 0.0, a1 = 0.0;
+    bool ok = false;
+    for (unsigned spins = 0; spins < (1u << 16) && !ok; ++spins) {
+        a0 = a1 = 0.0;
+        bool mine = true;
+        for (unsigned m = lane; m < ng; m += 64) {
+            const unsigned long long* q = base + (size_t)(g + NSHARD * m) * 4;
 #pragma unroll
-        for (int k = 0; k < TILE_Y; ++k) t += wsum2[lane][k];
-        if (t != 0.0)
-            __hip_atomic_fetch_add((lane == 0 ? target_v : target_w) + (wg_linear % NSHARD), t, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 0; k < NV; ++k) {
+                const unsigned long long lo = __hip_atomic_load(q + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(q + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mine = mine && (unsigned)(lo >> 32) == tag && (unsigned)(hi >> 32) == tag;
+                const double val = __longlong_as_double((long long)((hi << 32) | (lo & 0xffffffffull)));
+                if (k == 0) a0 += val; else a1 += val;
+            }
+        }
+        ok = __all(mine);
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+    }
+    a0 = wave_sum_l63(a0);
+    if (NV > 1) a1 = wave_sum_l63(a1);
+    if (lane == 63) {
+        const double bad = __longlong_as_double(0x7ff8000000000000ll);
+        tgt0[g] = ok ? a0 : bad;
+        if (NV > 1) tgt1[g] = ok ? a1 : bad;
+    }
+    if (lane == 0) {           // ready for the next launch (seen there after the kernel boundary)
+        __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tk + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

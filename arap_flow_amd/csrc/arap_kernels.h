@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256) void k_analyse(PlanDev pd, uint8_t* tile_activ
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
 {
     const VIdx v = vidx(pd);
-    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    double* const rho0 = pd.red + ((size_t)v.b * pd.nslots + 0) * NSHARD;
+    // (a workgroup with nothing to do still reports to the order-fixed sum: arap_device.h, block_reduce_fixed)
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) { block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, rho0, nullptr); return; }
     const Slot sl = pd.slots[v.b];
     const unsigned f = v.in ? pd.flags[v.g] : 0u;
     double d = 0.0;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
         pd.preO[v.g] = make_float2(0.f, 0.f);   // PCGInit1 stores pre = 0 on excluded vertices (:395)
         pd.preA[v.g] = 0.f;
     }
-    block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + 0) * NSHARD, v.wg);
+    block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, d, 0.0, rho0, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -183,7 +185,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
 {
     const VIdx v = vidx(pd);
-    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    double* const sigma_l = pd.red + ((size_t)v.b * pd.nslots + (2 * l + 1)) * NSHARD;
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) { block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, sigma_l, nullptr); return; }
     const Slot sl = pd.slots[v.b];
     const size_t gb = (size_t)v.b * pd.N;
     const float2* __restrict__ pinO = (l & 1) ? pd.pO1 : pd.pO0;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
         pd.ApA[v.g] = aa;
         d = (double)dot3(pO.x, pO.y, pA, ax, ay, aa);
     }
-    block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 1)) * NSHARD, v.wg);
+    block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, d, 0.0, sigma_l, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -265,7 +268,13 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_a(PlanDev pd, int l)
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
 {
     const VIdx v = vidx(pd);
-    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    double* const rho_next = pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD;
+    double* const q_next = pd.lm ? pd.lmred + (size_t)(l + 1) * NSHARD : nullptr;
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) {
+        if (pd.lm) block_reduce_fixed<2>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, rho_next, q_next);
+        else block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, rho_next, nullptr);
+        return;
+    }
     const float2* __restrict__ pO_ = (l & 1) ? pd.pO0 : pd.pO1;   // written by k_pcg_a(l)
     const float* __restrict__ pA_ = (l & 1) ? pd.pA0 : pd.pA1;
     const double* rs = pd.red + (size_t)v.b * pd.nslots * NSHARD;
@@ -299,11 +308,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_pcg_b(PlanDev pd, int l)
             q = (double)(0.5f * dot3(dO.x, dO.y, dA, rO.x + b.x, rO.y + b.y, rA + pd.bA[v.g]));
         }
     }
-    if (pd.lm)
-        block_reduce_atomic2(d, q, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD,
-                             pd.lmred + (size_t)(l + 1) * NSHARD, v.wg);
-    else
-        block_reduce_atomic(d, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD, v.wg);
+    if (pd.lm) block_reduce_fixed<2>(pd, v.b, v.lb, v.nlb, d, q, rho_next, q_next);
+    else block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, d, 0.0, rho_next, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -359,17 +365,7 @@ __global__ __launch_bounds__(256) void k_pcg_b4(PlanDev pd, int l)
         zO4[2 * q] = *(float4*)&z[0]; zO4[2 * q + 1] = *(float4*)&z[4];
         dA4[q] = *(float4*)dla; rA4[q] = *(float4*)ra; zA4[q] = *(float4*)za;
     }
-    // block reduction (4 wavefronts of a 1-D block)
-    __shared__ double wsum[4];
-    d = wave_sum(d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        if (t != 0.0)
-            __hip_atomic_fetch_add(pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD + (blockIdx.x % NSHARD), t,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    block_reduce_fixed<1>(pd, b, blockIdx.x, gridDim.x, d, 0.0, pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -425,7 +421,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_cost(PlanDev pd, int cost_in
         }
         d = (double)(0.5f * t);
     }
-    block_reduce_atomic(d, pd.costred + ((size_t)v.b * pd.ncost + cost_index) * NSHARD, v.wg);
+    block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, d, 0.0, pd.costred + ((size_t)v.b * pd.ncost + cost_index) * NSHARD, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

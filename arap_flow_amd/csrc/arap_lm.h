@@ -42,7 +42,8 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_prepare(PlanDev pd, float
                                                                 int first)
 {
     const VIdx v = vidx(pd);
-    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    double* const rho0 = pd.red + ((size_t)v.b * pd.nslots + 0) * NSHARD;
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) { block_reduce_fixed<2>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, rho0, pd.lmred); return; }
     const Slot sl = pd.slots[v.b];
     const unsigned f = v.in ? pd.flags[v.g] : 0u;
     double d = 0.0, q = 0.0;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_prepare(PlanDev pd, float
         const float2 dl = pd.deltaO[v.g];
         q = (double)(0.5f * dot3(dl.x, dl.y, pd.deltaA[v.g], r.x + r.x, r.y + r.y, ra + ra));
     }
-    block_reduce_atomic2(d, q, pd.red + ((size_t)v.b * pd.nslots + 0) * NSHARD, pd.lmred + (size_t)0 * NSHARD, v.wg);
+    block_reduce_fixed<2>(pd, v.b, v.lb, v.nlb, d, q, rho0, pd.lmred);
 }
 
 // out = J^T J in + CtC in   (computeAdelta :570-575); `in` may be any plan vector
@@ -144,7 +145,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_step2a(PlanDev pd, int l)
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_step2b(PlanDev pd, int l)
 {
     const VIdx v = vidx(pd);
-    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    double* const rho_next = pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD;
+    double* const q_next = pd.lmred + (size_t)(l + 1) * NSHARD;
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) { block_reduce_fixed<2>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, rho_next, q_next); return; }
     const unsigned f = v.in ? pd.flags[v.g] : 0u;
     double d = 0.0, q = 0.0;
     if (f & F_ACT) {
@@ -159,15 +162,14 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_step2b(PlanDev pd, int l)
         d = (double)dot3(zx, zy, za, rx, ry, ra);
         q = (double)(0.5f * dot3(dl.x, dl.y, dla, rx + b.x, ry + b.y, ra + ba));
     }
-    block_reduce_atomic2(d, q, pd.red + ((size_t)v.b * pd.nslots + (2 * l + 2)) * NSHARD,
-                         pd.lmred + (size_t)(l + 1) * NSHARD, v.wg);
+    block_reduce_fixed<2>(pd, v.b, v.lb, v.nlb, d, q, rho_next, q_next);
 }
 
 // computeModelCost: 0.5 * sum (F + J delta)^2 over the residuals centred on active vertices
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_model_cost(PlanDev pd, int slot)
 {
     const VIdx v = vidx(pd);
-    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) { block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, pd.lmred + (size_t)slot * NSHARD, nullptr); return; }
     const Slot sl = pd.slots[v.b];
     const unsigned f = v.in ? pd.flags[v.g] : 0u;
     double d = 0.0;
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_lm_model_cost(PlanDev pd, in
         }
         d = (double)(0.5f * t);
     }
-    block_reduce_atomic(d, pd.lmred + (size_t)slot * NSHARD, v.wg);
+    block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, d, 0.0, pd.lmred + (size_t)slot * NSHARD, nullptr);
 }
 
 }  // namespace arap

@@ -19,11 +19,12 @@
 namespace arap {
 
 // tile (tx, ty) and frame of a workgroup of a 1-D launch of nb * 8 * chunk blocks, chunk = ceil(tiles / 8)
-__device__ __forceinline__ bool xcd_tile(int tilesX, int tilesY, int chunk, int& tx, int& ty, int& b)
+__device__ __forceinline__ bool xcd_tile(int tilesX, int tilesY, int chunk, int& tx, int& ty, int& b, unsigned& lb)
 {
     const int bid = blockIdx.x;
     b = bid / (8 * chunk);
     const int r = bid - b * 8 * chunk;
+    lb = (unsigned)r;                                 // linear index among the frame's 8 * chunk workgroups
     const int tile = (r & 7) * chunk + (r >> 3);
     if (tile >= tilesX * tilesY) return false;
     ty = tile / tilesX;
@@ -34,13 +35,16 @@ __device__ __forceinline__ bool xcd_tile(int tilesX, int tilesY, int chunk, int&
 template <int TX, int TY>
 __global__ __launch_bounds__(TX* TY) void k_pcg_a_grid(PlanDev pd, int l, int tilesX, int tilesY, int chunk)
 {
-    constexpr int LW = TX + 2, LH = TY + 2, NW = TX * TY / 64;
+    constexpr int LW = TX + 2, LH = TY + 2;
     __shared__ float2 sP[LH * LW];
     __shared__ float2 sC[LH * LW];
     __shared__ float sA[LH * LW];
-    __shared__ double wsum[NW];
     int btx, bty, b;
-    if (!xcd_tile(tilesX, tilesY, chunk, btx, bty, b)) return;
+    unsigned lb;
+    const bool has_tile = xcd_tile(tilesX, tilesY, chunk, btx, bty, b, lb);
+    const unsigned nlb = 8u * (unsigned)chunk;
+    double* const sigma_l = pd.red + ((size_t)b * pd.nslots + (2 * l + 1)) * NSHARD;
+    if (!has_tile) { block_reduce_fixed<1>(pd, b, lb, nlb, 0.0, 0.0, sigma_l, nullptr); return; }
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int x = btx * TX + tx, y = bty * TY + ty;
     const int W = pd.W, H = pd.H;
@@ -48,7 +52,10 @@ __global__ __launch_bounds__(TX* TY) void k_pcg_a_grid(PlanDev pd, int l, int ti
     const int i = x + W * y;
     const size_t gb = (size_t)b * pd.N;
     const unsigned f = in ? pd.flags[gb + i] : 0u;
-    if (!__syncthreads_or((int)(f & F_ACT))) return;             // nothing active in this tile
+    if (!__syncthreads_or((int)(f & F_ACT))) {                   // nothing active in this tile
+        block_reduce_fixed<1>(pd, b, lb, nlb, 0.0, 0.0, sigma_l, nullptr);
+        return;
+    }
     const Slot sl = pd.slots[b];
     const float2* __restrict__ pinO = (l & 1) ? pd.pO1 : pd.pO0;
     const float* __restrict__ pinA = (l & 1) ? pd.pA1 : pd.pA0;
@@ -128,18 +135,7 @@ __global__ __launch_bounds__(TX* TY) void k_pcg_a_grid(PlanDev pd, int l, int ti
         pd.ApA[gb + i] = aa;
         d = (double)dot3(pO.x, pO.y, pA, ax, ay, aa);
     }
-    d = wave_sum(d);
-    const int lin = ty * TX + tx;
-    if ((lin & 63) == 0) wsum[lin >> 6] = d;
-    __syncthreads();
-    if (lin == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += wsum[w];
-        if (t != 0.0)
-            __hip_atomic_fetch_add(pd.red + ((size_t)b * pd.nslots + (2 * l + 1)) * NSHARD + (blockIdx.x % NSHARD), t,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    block_reduce_fixed<1>(pd, b, lb, nlb, d, 0.0, sigma_l, nullptr);
 }
 
 // Phase A as a MARCH down a 64-column strip: a workgroup of 4 wavefronts (one row of 64 vertices each) owns RB
@@ -157,9 +153,14 @@ __global__ __launch_bounds__(256) void k_pcg_a_march(PlanDev pd, int l, int stri
     __shared__ float2 sC[RROWS][LW];
     __shared__ float sA[RROWS][LW];
     __shared__ unsigned char sF[RROWS][TILE_X];
-    __shared__ double wsum[4];
     int sx, cy, b;
-    if (!xcd_tile(stripsX, chunksY, chunk8, sx, cy, b)) return;
+    unsigned lb;
+    const bool has_strip = xcd_tile(stripsX, chunksY, chunk8, sx, cy, b, lb);
+    const unsigned nlb = 8u * (unsigned)chunk8;
+    double* const sigma_l = pd.red + ((size_t)b * pd.nslots + (2 * l + 1)) * NSHARD;
+    // the tag of this launch's granules (order-fixed sum at the end): fetched now, used after the march
+    const unsigned rtag = red_tag(pd, b, lb);
+    if (!has_strip) { block_reduce_fixed<1>(pd, b, lb, nlb, 0.0, 0.0, sigma_l, nullptr, rtag); return; }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int W = pd.W, H = pd.H;
     const size_t gb = (size_t)b * pd.N;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void k_pcg_a_march(PlanDev pd, int l, int stri
     {
         bool any = false;
         for (int k = 0; k < nblk; ++k) any = any || active(k);
-        if (!any) return;
+        if (!any) { block_reduce_fixed<1>(pd, b, lb, nlb, 0.0, 0.0, sigma_l, nullptr, rtag); return; }
     }
     const Slot sl = pd.slots[b];
     const float2* __restrict__ pinO = (l & 1) ? pd.pO1 : pd.pO0;
@@ -299,15 +300,7 @@ __global__ __launch_bounds__(256) void k_pcg_a_march(PlanDev pd, int l, int stri
         finish(k + 2, nx);
         __syncthreads();
     }
-    d = wave_sum(d);
-    if (lane == 0) wsum[w] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        if (t != 0.0)
-            __hip_atomic_fetch_add(pd.red + ((size_t)b * pd.nslots + (2 * l + 1)) * NSHARD + (blockIdx.x % NSHARD), t,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    block_reduce_fixed<1>(pd, b, lb, nlb, d, 0.0, sigma_l, nullptr, rtag);
 }
 
 // Phase B (k_pcg_b4's update, four consecutive vertices per lane, 16-byte accesses) without the z and preO reads.
@@ -315,8 +308,8 @@ __global__ __launch_bounds__(256) void k_pcg_a_march(PlanDev pd, int l, int stri
 __global__ __launch_bounds__(256) void k_pcg_b4_lean(PlanDev pd, int l)
 {
     __shared__ float moLUT[12];
-    __shared__ double wsum[4];
     const int b = blockIdx.y;
+    const unsigned rtag = red_tag(pd, b, blockIdx.x);
     const int q = blockIdx.x * 256 + threadIdx.x;          // quad index
     const int nq = pd.N >> 2;
     const size_t gb = (size_t)b * pd.N;
@@ -380,15 +373,7 @@ __global__ __launch_bounds__(256) void k_pcg_b4_lean(PlanDev pd, int l)
         zO4[2 * q] = *(float4*)&z[0]; zO4[2 * q + 1] = *(float4*)&z[4];
         dA4[q] = *(float4*)dla; rA4[q] = *(float4*)ra; zA4[q] = *(float4*)za;
     }
-    d = wave_sum(d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double t = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-        if (t != 0.0)
-            __hip_atomic_fetch_add(pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD + (blockIdx.x % NSHARD), t,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    block_reduce_fixed<1>(pd, b, blockIdx.x, gridDim.x, d, 0.0, pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD, nullptr, rtag);
 }
 
 }  // namespace arap

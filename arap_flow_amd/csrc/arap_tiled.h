@@ -14,11 +14,10 @@ namespace arap {
 template <int TX, int TY>
 __global__ __launch_bounds__(TX* TY) void k_pcg_a_lds(PlanDev pd, int l)
 {
-    constexpr int LW = TX + 2, LH = TY + 2, NW = TX * TY / 64;
+    constexpr int LW = TX + 2, LH = TY + 2;
     __shared__ float2 sP[LH * LW];
     __shared__ float2 sC[LH * LW];
     __shared__ float sA[LH * LW];
-    __shared__ double wsum[NW];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int x = blockIdx.x * TX + tx, y = blockIdx.y * TY + ty, b = blockIdx.z;
     const int W = pd.W, H = pd.H;
@@ -26,8 +25,12 @@ __global__ __launch_bounds__(TX* TY) void k_pcg_a_lds(PlanDev pd, int l)
     const int i = x + W * y;
     const size_t gb = (size_t)b * pd.N;
     const unsigned f = in ? pd.flags[gb + i] : 0u;
-    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x;
-    if (!__syncthreads_or((int)(f & F_ACT))) return;             // nothing active in this tile
+    const unsigned wg = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+    double* const sigma_l = pd.red + ((size_t)b * pd.nslots + (2 * l + 1)) * NSHARD;
+    if (!__syncthreads_or((int)(f & F_ACT))) {                   // nothing active in this tile (it still reports: block_reduce_fixed)
+        block_reduce_fixed<1>(pd, b, wg, nwg, 0.0, 0.0, sigma_l, nullptr);
+        return;
+    }
     const Slot sl = pd.slots[b];
     const float2* __restrict__ pinO = (l & 1) ? pd.pO1 : pd.pO0;
     const float* __restrict__ pinA = (l & 1) ? pd.pA1 : pd.pA0;
@@ -109,18 +112,7 @@ __global__ __launch_bounds__(TX* TY) void k_pcg_a_lds(PlanDev pd, int l)
         pd.ApA[gb + i] = aa;
         d = (double)dot3(pO.x, pO.y, pA, ax, ay, aa);
     }
-    d = wave_sum(d);
-    const int lin = ty * TX + tx;
-    if ((lin & 63) == 0) wsum[lin >> 6] = d;
-    __syncthreads();
-    if (lin == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) t += wsum[w];
-        if (t != 0.0)
-            __hip_atomic_fetch_add(pd.red + ((size_t)b * pd.nslots + (2 * l + 1)) * NSHARD + (wg % NSHARD), t,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    block_reduce_fixed<1>(pd, b, wg, nwg, d, 0.0, sigma_l, nullptr);
 }
 
 }  // namespace arap

@@ -190,7 +190,12 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     const size_t sz2 = align_up(BN * sizeof(float2), 256), sz1 = align_up(BN * sizeof(float), 256);
     const size_t szf = align_up(BN, 256), szt = align_up((size_t)batch * pd.tilesX * pd.tilesY, 256);
     const size_t szs = align_up(sizeof(Slot) * batch, 256);
-    const size_t total = 8 * sz2 + 7 * sz1 + szf + szt + szs;
+    // order-fixed reductions (arap_device.h: block_reduce_fixed): a slot per workgroup of the largest launch of any
+    // kernel of this plan -- every tile shape is at least 16 wide and 4 high -- and the groups' tickets
+    pd.maxblk = ((W + 15) / 16) * ((H + 3) / 4) + 16;
+    const size_t szp = align_up((size_t)batch * pd.maxblk * 4 * sizeof(unsigned long long), 256);
+    const size_t szk = align_up((size_t)batch * NSHARD * 2 * sizeof(unsigned), 256);
+    const size_t total = 8 * sz2 + 7 * sz1 + szf + szt + szs + szp + szk;
     HC(hipMalloc(&p->block, total));
     HC(hipMemsetAsync(p->block, 0, total, st->stream));
     char* c = (char*)p->block;
@@ -204,6 +209,8 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     pd.flags = (uint8_t*)take(szf);
     pd.tileact = (uint8_t*)take(szt);
     pd.slots = (Slot*)take(szs);
+    pd.part = (unsigned long long*)take(szp);
+    pd.tick = (unsigned*)take(szk);
     pd.red = nullptr; pd.costred = nullptr; pd.nslots = 0; pd.ncost = 0;
     p->hslots.assign(batch, Slot{});
     p->h_ntiles.assign(batch, 0);
@@ -917,9 +924,10 @@ static int plan_step(Opt_Plan* p)
     if (p->sp.nIter < p->sp.nIterations) {
         plan_upload_slots(p);
         // the caller may have changed Mask / UrShape since Init or the last Step (Opt.h:58-66)
-        if (!p->res_frames &&
-            (p->sp.nIter == 0 || (p->res_capable && p->st->use_resident && p->st->res_cooldown == 0)))
-            plan_analyse_for_resident(p);
+        // -- looked at before EVERY step, whatever path the step will take: grid_u (no UrShape loads in phase A of the
+        // two-kernel path) is a property of the images as they are NOW, also with the resident kernel switched off,
+        // paused after a timeout or absent on this device.
+        if (!p->res_frames) plan_analyse_for_resident(p);
         const bool used_res = plan_resident_eligible(p);
         plan_gn_step(p);
         if (used_res && (!p->res_frames || p->st->verbosity > 0)) {
@@ -1459,6 +1467,7 @@ struct ArapFlow_Solver {
     bool uploads_pending = false;    // SetFrame since the last solve: the solve waits for ev_up
     bool inflight = false;           // a solve has been enqueued and not waited for
     bool retried = false;            // the last wait redid the schedule on the two-kernel path
+    unsigned launches_at_enqueue = 0; // plan->res_launches when the pending solve call was enqueued
     unsigned a_n = 0, a_numIter = 0, a_nIt = 0, a_lIt = 0;
     int a_warp = 0, a_download = 0;
 };
@@ -1626,7 +1635,7 @@ int ArapFlow_SolverSetFrame(ArapFlow_Solver* s, unsigned slot, const uint8_t* rg
 {
     if (!s || slot >= (unsigned)s->batch || !mask_red || (ncons && !cons)) return -1;
     // the previous solve of THIS solver may still read the slot's images and tile lists
-    if (s->inflight && ArapFlow_SolverWait(s) != 0) return -1;
+    if (s->inflight) { const int rc = ArapFlow_SolverWait(s); if (rc != 0) return rc; }     // (-2: the retry failed too)
     const int W = s->W, H = s->H;
     const size_t N = s->N;
     // the staging of this slot may still be the source of an earlier upload
@@ -1703,6 +1712,7 @@ int ArapFlow_SolverSolveAsync(ArapFlow_Solver* s, unsigned nframes, unsigned num
     s->a_n = nframes; s->a_numIter = numIter; s->a_nIt = nIterations; s->a_lIt = lIterations;
     s->a_warp = warp; s->a_download = download;
     s->retried = false;
+    s->launches_at_enqueue = s->plan->res_launches;
     solver_enqueue(s);
     if (paused) --st->res_cooldown;
     s->inflight = true;
@@ -1732,8 +1742,8 @@ int ArapFlow_SolverWait(ArapFlow_Solver* s)
             s->inflight = false;
             return -2;
         }
-    } else if (p->res_launches > 0) {
-        st->res_backoff = 8;
+    } else if (p->res_launches != s->launches_at_enqueue) {
+        st->res_backoff = 8;                                  // a CHECKED resident success (this call launched the kernel)
     }
     if (s->a_download) HC(hipEventSynchronize(s->ev_dl));
     s->inflight = false;
@@ -1750,8 +1760,13 @@ int ArapFlow_SolverSolve(ArapFlow_Solver* s, unsigned nframes, unsigned numIter,
 int ArapFlow_SolverWarp(ArapFlow_Solver* s, unsigned nframes)
 {
     if (!s || nframes == 0 || nframes > (unsigned)s->batch) return -1;
-    if (s->inflight && ArapFlow_SolverWait(s) != 0) return -1;
+    if (s->inflight) { const int rc = ArapFlow_SolverWait(s); if (rc != 0) return rc; }
     solver_enqueue_warp(s, nframes);
+    // the rasteriser reads the slots' mask / rgb and rewrites their outputs: every later call on this solver that touches
+    // them (SetFrame, GetResults, ...) waits for it like for a solve
+    HC(hipEventRecord(s->ev_done, s->st->stream));
+    s->launches_at_enqueue = s->plan->res_launches;
+    s->inflight = true;
     return 0;
 }
 

@@ -267,7 +267,15 @@ int main(int argc, const char* argv[])
     // Frames per solve call: the library gives every solve a group of the resident launch's workgroups sized by its
     // active tiles and a launch costs the same however full it is, so frames join a batch while they still fit ONE
     // launch (ArapFlow_SolverLaunchesFor); minFill frames per call when the resident kernel does not apply.
-    const unsigned maxBatch = 32, minFill = 8;
+    // Both bounds follow the frame size: a solver object pins 24 bytes x vertices x maxBatch of host staging (two objects:
+    // 0.6 GB at 854x480 x 32 -- but 3.2 GB at 1920x1080 x 32, where a launch holds four segment solves anyway).
+    auto max_batch_for = [](int w, int h) -> unsigned {
+        const double rel = (double)w * h / (854.0 * 480.0);
+        const int m = (int)(32.0 / (rel < 1.0 ? 1.0 : rel));
+        return (unsigned)(m < 8 ? 8 : m);
+    };
+    unsigned maxBatch = 32;
+    const unsigned minFill = 8;
     // --serve: how long a partly filled batch waits for another line when the GPU is idle
     int linger_ms = 30;
     if (const char* e = getenv("ARAP_DEFORM_LINGER_MS")) linger_ms = atoi(e);
@@ -346,6 +354,7 @@ int main(int argc, const char* argv[])
                     ArapFlow_SolverFree(lanes[0].solver);
                     ArapFlow_SolverFree(lanes[1].solver);
                 }
+                maxBatch = max_batch_for(w, h);
                 lanes[0].solver = ArapFlow_SolverCreate(state, (unsigned)w, (unsigned)h, maxBatch);
                 lanes[1].solver = ArapFlow_SolverCreate(state, (unsigned)w, (unsigned)h, maxBatch);
                 if (!lanes[0].solver || !lanes[1].solver) { rc = 1; break; }

@@ -1,20 +1,20 @@
 """Python 3 host side of the dataset generator, over libarapopt.so.
 
-Mirrors, function for function, what the reference's Python 2 scripts and C++ drivers do AROUND the hot
-path:
+What the reference's Python 2 scripts and C++ drivers do AROUND the hot path, written from their
+behaviour (the contract each function states in its docstring), with the size / selection arithmetic as pure
+functions that tests/golden/host/ pins with hand-computed cases:
   read_list / deform_list   ARAP/deformation/src/main.cpp:162-241  (arap_deform: 6 paths per line)
   warp_files                ARAP/warping/src/main.cpp:302-336      (warp_image)
-  fit_bg, add_bg            para_gen.py:36-61
-  flatten                   para_gen.py:136-175   (--multseg: merge per-segment outputs by the warped masks)
-  valid_cnstr               para_gen.py:216-223
-  scale_rotate              para_gen.py:253-291
-  make_arap_path            para_gen.py:331-339
+  cover_scale, fit_bg, add_bg            para_gen.py:36-61      (background compositing)
+  merge_segments, flatten                para_gen.py:136-175    (--multseg: merge per-segment outputs by the warped masks)
+  match_ok, valid_cnstr, filter_matches  para_gen.py:216-223,468-482
+  resize_crop_geometry, scale_rotate     para_gen.py:253-291
+  make_arap_path                         para_gen.py:331-339
 No oracle import; the solve and the rasteriser run on the GPU through arap_flow_amd.opt.
 """
 import os
 import os.path as osp
 import random as rn
-from math import sqrt
 
 import numpy as np
 from PIL import Image
@@ -178,52 +178,81 @@ def warp_files(state, rgb_path, mask_path, flo_path, out_rgb_path, out_mask_path
 # ------------------------------------------------------------------------------------------------------
 # para_gen helpers
 # ------------------------------------------------------------------------------------------------------
+def cover_scale(bg_hw, im_hw, u):
+    """Background compositing, size arithmetic (behaviour of /root/reference/para_gen.py:36-48): the background is
+    enlarged by u (a draw from U(1, 2)) times the smallest factor that makes it cover the image in both directions
+    (never shrunk below its own size); sizes truncate.  Returns the enlarged (height, width)."""
+    (bh, bw), (ih, iw) = bg_hw, im_hw
+    cover = max(max(bh, ih) / float(bh), max(bw, iw) / float(bw))
+    return int(bh * (u * cover)), int(bw * (u * cover))
+
+
 def fit_bg(bg, im, rng=rn):
-    """para_gen.py:36-48"""
-    imh, imw = im.shape[:2]
-    bgh, bgw = bg.shape[:2]
-    bgim = Image.fromarray(bg)
-    hmax, wmax = max(bgh, imh), max(bgw, imw)
-    r = rng.uniform(1, 2) * max(float(hmax) / bgh, float(wmax) / bgw)
-    bgim = bgim.resize((int(bgw * r), int(bgh * r)), _ANTIALIAS)
-    bg = np.array(bgim)
-    sy, sx = rng.randint(0, bg.shape[0] - imh), rng.randint(0, bg.shape[1] - imw)
-    return bg[sy:(sy + imh), sx:(sx + imw), :]
+    """A random window of an enlarged copy of `bg`, as large as `im`.  Three draws from `rng`, in this order (so that a
+    seeded run picks the windows the reference would): the enlargement u = uniform(1, 2), then the window's top row and
+    its left column, each randint over every position that keeps the window inside (both ends included)."""
+    ih, iw = im.shape[:2]
+    u = rng.uniform(1, 2)
+    nh, nw = cover_scale(bg.shape[:2], (ih, iw), u)
+    big = np.asarray(Image.fromarray(bg).resize((nw, nh), _ANTIALIAS))
+    top = rng.randint(0, big.shape[0] - ih)
+    left = rng.randint(0, big.shape[1] - iw)
+    return big[top:top + ih, left:left + iw, :]
 
 
 def add_bg(im, mk, bgim, bgval=0):
-    """para_gen.py:50-61"""
-    assert mk.shape == im.shape[:-1], "Sizes mismatch mask and image %s vs. %s" % (mk.shape, im.shape[:-1])
-    assert bgim.shape == im.shape, "Sizes mismatch background and image %s vs. %s" % (bgim.shape, im.shape)
-    out = im.copy()
-    idx = mk == bgval
-    if len(out.shape) == 3:
-        out[idx] = bgim[idx]
-    else:
-        out = bgim
-    return out
+    """Composite: pixels whose mask value equals `bgval` come from `bgim`, all others from `im`
+    (/root/reference/para_gen.py:50-61).  `im` and `bgim` are (H, W, C) of one shape, `mk` is (H, W)."""
+    if im.ndim != 3 or mk.shape != im.shape[:2]:
+        raise AssertionError("Sizes mismatch mask and image %s vs. %s" % (mk.shape, im.shape[:-1]))
+    if bgim.shape != im.shape:
+        raise AssertionError("Sizes mismatch background and image %s vs. %s" % (bgim.shape, im.shape))
+    return np.where((mk == bgval)[..., None], bgim, im).astype(im.dtype, copy=False)
+
+
+MAX_MATCH_DIST = 60          # a match moves less than this many pixels ...
+
+
+def match_ok(xy1, xy2, msk1, msk2):
+    """Which matches become constraints (/root/reference/para_gen.py:216-223)?  xy1, xy2: integer arrays (n, 2) of
+    (x, y) in the first / second frame.  A match is kept when both ends lie inside their label masks, it moves by more
+    than nothing and by less than MAX_MATCH_DIST pixels (Euclidean; compared as squared integers, which is the same
+    predicate), its source lies on a segment (label > 0) and both ends carry the same label.  Returns a bool array.
+    (Negative coordinates are rejected here; the reference would index from the far edge, which no matcher output
+    can mean.)"""
+    xy1 = np.asarray(xy1, np.int64).reshape(-1, 2)
+    xy2 = np.asarray(xy2, np.int64).reshape(-1, 2)
+    (h1, w1), (h2, w2) = msk1.shape[:2], msk2.shape[:2]
+    inside = ((xy1 >= 0).all(1) & (xy2 >= 0).all(1) &
+              (xy1[:, 0] < w1) & (xy1[:, 1] < h1) & (xy2[:, 0] < w2) & (xy2[:, 1] < h2))
+    d2 = ((xy2 - xy1) ** 2).sum(1)
+    keep = inside & (d2 > 0) & (d2 < MAX_MATCH_DIST ** 2)
+    lab1 = np.zeros(len(xy1), msk1.dtype)
+    lab2 = np.zeros(len(xy1), msk2.dtype)
+    lab1[inside] = msk1[xy1[inside, 1], xy1[inside, 0]]
+    lab2[inside] = msk2[xy2[inside, 1], xy2[inside, 0]]
+    return keep & (lab1 > 0) & (lab1 == lab2)
 
 
 def valid_cnstr(x1, y1, x2, y2, msk1, msk2):
-    """para_gen.py:216-223: in range, 0 < |d| < 60, on a segment, same label in both masks"""
-    if x1 >= msk1.shape[1] or x2 >= msk2.shape[1] or y1 >= msk1.shape[0] or y2 >= msk2.shape[0]:
-        return False
-    dist = sqrt((x2 - x1) ** 2 + (y2 - y1) ** 2)
-    return bool(dist < 60 and dist > 0 and msk1[y1, x1] > 0 and msk1[y1, x1] == msk2[y2, x2])
+    """one match (the reference's call shape, para_gen.py:216-223)"""
+    return bool(match_ok([(x1, y1)], [(x2, y2)], msk1, msk2)[0])
 
 
 def filter_matches(match_lines, mk1, mk2):
-    """para_gen.py:468-482: keep valid matches; returns (constraint rows, label of each kept row)"""
-    cstrs, valids = [], []
+    """para_gen.py:468-482: the matcher's lines `x1 y1 x2 y2 score index` -> (constraint rows, label of each kept row),
+    in the matcher's order"""
+    rows = []
     for line in match_lines:
         tok = line.split()
-        if len(tok) < 4:
-            continue
-        x1, y1, x2, y2 = [int(float(t)) for t in tok[:4]]
-        if valid_cnstr(x1, y1, x2, y2, mk1, mk2):
-            cstrs.append((x1, y1, x2, y2))
-            valids.append(int(mk1[y1, x1]))
-    return cstrs, valids
+        if len(tok) >= 4:
+            rows.append([int(float(t)) for t in tok[:4]])
+    if not rows:
+        return [], []
+    a = np.asarray(rows, np.int64)
+    keep = match_ok(a[:, 0:2], a[:, 2:4], mk1, mk2)
+    kept = a[keep]
+    return [tuple(int(v) for v in r) for r in kept], [int(mk1[r[1], r[0]]) for r in kept]
 
 
 def write_constraints(path, cstrs):
@@ -232,25 +261,41 @@ def write_constraints(path, cstrs):
         f.write("\n".join([str(len(cstrs))] + ["\t".join("%d" % v for v in c) for c in cstrs]))
 
 
+def resize_crop_geometry(in_size, out_size, margin=10):
+    """Frame preparation, size arithmetic (behaviour of /root/reference/para_gen.py:275-287).  in_size, out_size:
+    (width, height).  The frame is scaled by the one factor that makes it at least `margin` pixels larger than the
+    target in both directions (sizes truncate) and the target window is cut around the centre: left = floor(w / 2) -
+    floor(target_w / 2), likewise the top.  Returns ((w, h), (left, upper, right, lower))."""
+    (iw, ih), (ow, oh) = in_size, out_size
+    r = max((ow + margin) / float(iw), (oh + margin) / float(ih))
+    w, h = int(iw * r), int(ih * r)
+    left, upper = w // 2 - ow // 2, h // 2 - oh // 2
+    return (w, h), (left, upper, left + ow, upper + oh)
+
+
+def _is_jpeg(path):
+    ext = osp.splitext(path)[1].upper()
+    return "JPG" in ext or "JPEG" in ext
+
+
 def scale_rotate(im_path, mk_path, size=None):
-    """para_gen.py:253-291.  Returns (preprocessed, image, mask) as PIL images."""
+    """Open a frame and its label mask and bring them to the working format (/root/reference/para_gen.py:253-291):
+    portrait frames are transposed to landscape; with a target `size` (w, h) every frame of another size is scaled
+    (image: antialiased, mask: nearest neighbour) and centre-cropped by resize_crop_geometry.  Returns (changed, image,
+    mask) as PIL images; `changed` is also true for JPEG inputs, which the caller then re-encodes as PNG."""
     im, mk = Image.open(im_path), Image.open(mk_path)
-    assert im.size == mk.size, "Image and mask must be of the same size but given %s vs. %s" % (im.size, mk.size)
-    ext = "%s %s" % (osp.splitext(im_path)[1], osp.splitext(mk_path)[1])
-    preprocessed = "JPG" in ext.upper() or "JPEG" in ext.upper()
-    if im.size[1] > im.size[0]:                       # portrait -> landscape
-        im, mk = im.transpose(Image.TRANSPOSE), mk.transpose(Image.TRANSPOSE)
-        preprocessed = True
-    if size is not None and im.size != tuple(size):
-        r = max(float(size[0] + 10) / float(im.size[0]), float(size[1] + 10) / float(im.size[1]))
-        w, h = (np.array(im.size) * r).astype(int)
-        im = im.resize((int(w), int(h)), _ANTIALIAS)
-        mk = mk.resize((int(w), int(h)), Image.NEAREST)
-        left, upper = int(w / 2) - size[0] // 2, int(h / 2) - size[1] // 2
-        box = (left, upper, left + size[0], upper + size[1])
-        im, mk = im.crop(box), mk.crop(box)
-        preprocessed = True
-    return preprocessed, im, mk
+    if im.size != mk.size:
+        raise AssertionError("Image and mask must be of the same size but given %s vs. %s" % (im.size, mk.size))
+    changed = _is_jpeg(im_path) or _is_jpeg(mk_path)
+    if im.height > im.width:
+        im, mk = (x.transpose(Image.TRANSPOSE) for x in (im, mk))
+        changed = True
+    if size is not None and tuple(im.size) != tuple(size):
+        new_size, box = resize_crop_geometry(im.size, tuple(size))
+        im = im.resize(new_size, _ANTIALIAS).crop(box)
+        mk = mk.resize(new_size, Image.NEAREST).crop(box)
+        changed = True
+    return changed, im, mk
 
 
 def make_arap_path(p):
@@ -279,36 +324,42 @@ def split_segments(mk1, valid_labels):
     return out
 
 
+def merge_segments(flows, rgbs, masks):
+    """--multseg: the per-segment results of one frame, stacked (segment, H, W, ...), become one result: at every pixel
+    the LAST segment after the first whose warped mask is set wins, and the first segment fills the rest
+    (/root/reference/para_gen.py:136-175, which folds the segments in with `old * (mask == 0) + new * (mask != 0)`: the
+    same selection, up to the sign of a zero flow and non-finite values under a cleared mask)."""
+    masks = np.asarray(masks)
+    n = masks.shape[0]
+    on = masks != 0
+    on[0] = True                                               # the first segment is the base layer
+    winner = (n - 1) - np.argmax(on[::-1], axis=0)             # last segment with its mask set
+    pick = winner[None, ...]
+    flow = np.take_along_axis(np.asarray(flows), pick[..., None], axis=0)[0]
+    rgb = np.take_along_axis(np.asarray(rgbs), pick[..., None], axis=0)[0]
+    mask = np.take_along_axis(masks, pick, axis=0)[0]
+    return flow, rgb, mask
+
+
 def flatten(arap_seg_paths, remove=True):
-    """para_gen.py:136-175: merge the per-segment flow / warped RGB / warped mask files of each frame, later
-    segments overwriting earlier ones where their warped mask is set.  Returns the frames' list lines."""
-    for arap_path, seg_paths in arap_seg_paths:
-        assert len(seg_paths) > 0, "Something wrong with seg_paths"
-        flow_path, rgb2_path, msk2_path = seg_paths[0].split(" ")[-3:]
-        flow_im = flo.flow_read(flow_path)
-        rgb2_im = np.array(Image.open(rgb2_path))
-        msk2_im = np.array(Image.open(msk2_path))
-        if rgb2_im.ndim == 2:
-            rgb2_im = rgb2_im[..., None]
+    """para_gen.py:136-175 at file level: for every (frame line, [segment lines]) read the segments' flow / warped RGB /
+    warped mask files (the last three paths of a list line), merge them (merge_segments), write the frame's three
+    files, delete the segments' files.  Returns the frames' list lines."""
+    for frame_line, seg_lines in arap_seg_paths:
+        if len(seg_lines) == 0:
+            raise AssertionError("Something wrong with seg_paths")
+        files = [ln.split(" ")[-3:] for ln in seg_lines]
+        flows = [flo.flow_read(f) for f, _, _ in files]
+        rgbs = [np.asarray(Image.open(r)) for _, r, _ in files]
+        rgbs = [a[..., None] if a.ndim == 2 else a for a in rgbs]
+        masks = [np.asarray(Image.open(m)) for _, _, m in files]
+        flow, rgb, mask = merge_segments(flows, rgbs, masks)
         if remove:
-            for q in (flow_path, rgb2_path, msk2_path):
-                os.remove(q)
-        for sp in seg_paths[1:]:
-            flow_path, rgb2_path, msk2_path = sp.split(" ")[-3:]
-            flow_ = flo.flow_read(flow_path)
-            rgb2_ = np.array(Image.open(rgb2_path))
-            msk2_ = np.array(Image.open(msk2_path))
-            msk_ob, msk_bg = msk2_ != 0, msk2_ == 0
-            if rgb2_.ndim == 2:
-                rgb2_ = rgb2_[..., None]
-            flow_im = flow_im * msk_bg[..., None] + flow_ * msk_ob[..., None]
-            rgb2_im = rgb2_im * msk_bg[..., None] + rgb2_ * msk_ob[..., None]
-            msk2_im = msk2_im * msk_bg + msk2_ * msk_ob
-            if remove:
-                for q in (flow_path, rgb2_path, msk2_path):
+            for trio in files:
+                for q in trio:
                     os.remove(q)
-        out = arap_path.split(" ")
-        flo.flow_write(out[-3], flow_im)
-        Image.fromarray(rgb2_im.astype(np.uint8).squeeze()).save(out[-2])
-        Image.fromarray(msk2_im.astype(np.uint8)).save(out[-1])       # 0/1 valued, as the reference writes it
+        out_flow, out_rgb, out_mask = frame_line.split(" ")[-3:]
+        flo.flow_write(out_flow, flow)
+        Image.fromarray(rgb.astype(np.uint8).squeeze()).save(out_rgb)
+        Image.fromarray(mask.astype(np.uint8)).save(out_mask)     # a 1-bit mask file comes out 0 / 1 valued, as in the reference
     return [e[0] for e in arap_seg_paths]

@@ -338,6 +338,26 @@ def test_real_group_wait_timeout_and_recovery(tmp_path):
     assert r.stderr.count("gave up at a group wait") == 1
 
 
+
+def test_drop_in_steps_during_the_pause_after_a_timeout_see_urshape_change(tmp_path):
+    """ARAPOPT_FORCE_RES_FAIL=2: the first resident launch of a drop-in plan times out for real, the Step is redone on
+    the two-kernel path and the resident path pauses.  During the pause every Step must still look at UrShape: it
+    turns generic in place before the third Step, and the result must be the oracle's."""
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import test_gpu_solve as T\n"
+        "from arap_flow_amd import opt\n"
+        "from oracle import oracle as orc\n"
+        "st = opt.State()\n"
+        "T._stepwise_with_urshape_turning_generic(st, orc, expect_resident=True)\n"
+        "assert st.lib.ArapFlow_ResidentFailed(st.handle) == 1\n"
+        "print('pause ok')\n" % (ROOT, osp.join(ROOT, "tests")))
+    env = dict(os.environ, ARAPOPT_FORCE_RES_FAIL="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "pause ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stderr.count("gave up at a group wait") == 1
+
+
 def test_para_gen_hands_the_gpu_full_batches(tmp_path):
     """The real CLI must feed the kernel what bench.py measures: through `para_gen.py --matches` with the persistent
     C++ worker, 854x480 DAVIS-shaped pairs reach the GPU in batches of 8 (one resident launch); the mean batch over

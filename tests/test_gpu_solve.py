@@ -533,3 +533,54 @@ def test_drop_in_step_sees_mask_and_urshape_changed_in_place(gpu_state, oracle):
     assert np.array_equal(dev["O"].cpu().numpy(), O3) and np.array_equal(dev["A"].cpu().numpy(), A3)
     assert s.step(pp) == 0
     s.close()
+
+
+
+def _stepwise_with_urshape_turning_generic(state, oracle, expect_resident):
+    """Init + three Steps of a drop-in plan; before the third Step UrShape turns generic IN PLACE.  Returns nothing,
+    asserts the oracle's bits after every Step."""
+    W, H = 300, 150
+    pb = helpers.random_problem(W, H, seed=92, generic_urshape=False, mask_frac=0.0, ncons=80)
+    M1 = np.full((H, W), 255.0, np.float32); M1[20:90, 30:170] = 0.0
+    M2 = np.full((H, W), 255.0, np.float32); M2[60:140, 120:290] = 0.0
+    dev = {k: torch.from_numpy(pb[k].copy()).cuda() for k in "OAUC"}
+    dev["M"] = torch.from_numpy(M1.copy()).cuda()
+    s = opt.OptSolver(state, (W, H))
+    pp = opt.NamedParameters()
+    for n, k in [("Offset", "O"), ("Angle", "A"), ("UrShape", "U"), ("Constraints", "C"), ("Mask", "M")]:
+        pp.set(n, dev[k])
+    pp.set("w_fitSqrt", 10.0); pp.set("w_regSqrt", 0.1)
+    sp = opt.NamedParameters()
+    sp.set("nIterations", 3); sp.set("lIterations", 30)
+    s.set_solver_parameters(sp)
+    s.init(pp)
+    n0 = s.resident_launches()
+    assert s.step(pp) == 1
+    assert (s.resident_launches() > n0) == expect_resident
+    O1, A1, c1 = oracle.solve(pb["O"], pb["A"], pb["U"], pb["C"], M1, 10.0, 0.1, 1, 30, dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(dev["O"].cpu().numpy(), O1) and np.array_equal(dev["A"].cpu().numpy(), A1)
+    dev["M"].copy_(torch.from_numpy(M2)); torch.cuda.synchronize()            # new mask, same buffer
+    assert s.step(pp) == 1
+    O2, A2, c2 = oracle.solve(O1, A1, pb["U"], pb["C"], M2, 10.0, 0.1, 1, 30, dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(dev["O"].cpu().numpy(), O2) and np.array_equal(dev["A"].cpu().numpy(), A2)
+    # UrShape becomes generic in place.  The two-kernel path picks its phase-A kernel from the analysis of UrShape:
+    # a stale "UrShape is the pixel grid" would make phase A (no UrShape loads) disagree with k_gn_init (real UrShape).
+    U3 = pb["U"] + np.random.default_rng(6).normal(size=pb["U"].shape).astype(np.float32) * 0.2
+    dev["U"].copy_(torch.from_numpy(U3)); torch.cuda.synchronize()
+    n_res = s.resident_launches()
+    assert s.step(pp) == 1 and s.resident_launches() == n_res
+    O3, A3, c3 = oracle.solve(O2, A2, U3, pb["C"], M2, 10.0, 0.1, 1, 30, dtype=np.float32, mode=1, trig=1)
+    assert np.array_equal(dev["O"].cpu().numpy(), O3) and np.array_equal(dev["A"].cpu().numpy(), A3)
+    assert s.current_cost() == c3[-1]
+    assert s.step(pp) == 0
+    s.close()
+
+
+def test_drop_in_step_sees_urshape_changed_in_place_with_the_resident_kernel_off(gpu_state, oracle):
+    """The same protocol with ArapFlow_SetResident(state, 0): every Step runs on the two-kernel path, whose streaming
+    phase A applies only while UrShape is the pixel grid -- the analysis must run before EVERY step there too."""
+    gpu_state.set_resident(False)
+    try:
+        _stepwise_with_urshape_turning_generic(gpu_state, oracle, expect_resident=False)
+    finally:
+        gpu_state.set_resident(True)

@@ -212,3 +212,117 @@ def test_para_gen_fails_promptly_when_the_arap_worker_dies(tmp_path, worker):
     finally:
         os.chdir(cwd)
     assert time.time() - t0 < 60
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# hand-computed fixtures for the helpers around the hot path (tests/golden/host/cases.json)
+# ---------------------------------------------------------------------------------------------------------------------
+from arap_flow_amd import pipeline  # noqa: E402
+
+
+def _host_cases():
+    import json
+    return json.load(open(osp.join(ROOT, "tests", "golden", "host", "cases.json")))
+
+
+def test_resize_crop_geometry_hand_cases():
+    for c in _host_cases()["resize_crop_geometry"]:
+        new, box = pipeline.resize_crop_geometry(tuple(c["in"]), tuple(c["out"]))
+        assert list(new) == c["new"] and list(box) == c["box"], c
+        assert box[2] - box[0] == c["out"][0] and box[3] - box[1] == c["out"][1]
+
+
+def test_cover_scale_hand_cases():
+    for c in _host_cases()["cover_scale_hw"]:
+        assert list(pipeline.cover_scale(tuple(c["bg"]), tuple(c["im"]), c["u"])) == c["new"], c
+
+
+def test_match_filter_hand_cases():
+    mc = _host_cases()["match_ok"]
+    W, H = mc["labels_wh"]
+    lab = np.zeros((H, W), np.uint8)
+    for bx in mc["label_boxes"]:
+        lab[bx["y"][0]:bx["y"][1], bx["x"][0]:bx["x"][1]] = bx["label"]
+    for c in mc["cases"]:
+        assert pipeline.valid_cnstr(*c["m"], lab, lab) is c["ok"], c
+    ones = np.ones((200, 200), np.uint8)
+    for c in mc["distance_cases_on_all_ones_200x200"]:
+        assert pipeline.valid_cnstr(*c["m"], ones, ones) is c["ok"], c
+    # the vectorised form gives the same answers, in order, and filter_matches keeps the matcher's order
+    ms = np.asarray([c["m"] for c in mc["cases"]])
+    assert pipeline.match_ok(ms[:, :2], ms[:, 2:], lab, lab).tolist() == [c["ok"] for c in mc["cases"]]
+    lines = ["%d %d %d %d 0.9 %d" % (*c["m"], i) for i, c in enumerate(mc["cases"]) if min(c["m"]) >= 0]
+    rows, labels = pipeline.filter_matches(lines, lab, lab)
+    assert rows == [tuple(c["m"]) for c in mc["cases"] if c["ok"]] and labels == [1, 2]
+
+
+def test_merge_segments_hand_case(tmp_path):
+    mc = _host_cases()["merge_segments"]
+    masks = np.asarray(mc["masks"], np.uint8)
+    S, H, W = masks.shape
+    flows = np.stack([np.broadcast_to(np.asarray(f, np.float32), (H, W, 2)) for f in mc["flow_of_segment"]])
+    rgbs = np.stack([np.full((H, W, 3), v, np.uint8) for v in mc["rgb_of_segment"]])
+    flow, rgb, mask = pipeline.merge_segments(flows, rgbs, masks)
+    win = np.asarray(mc["winner"])
+    assert np.array_equal(flow[..., 0], win + 1.0) and np.array_equal(flow[..., 1], -(win + 1.0))
+    assert np.array_equal(rgb[..., 0], 10 * (win + 1)) and np.array_equal(mask, np.asarray(mc["mask_out"]))
+    # 1-bit mask files (what the C++ driver and LodePNG write) read back as bool: same selection
+    f2, r2, m2 = pipeline.merge_segments(flows, rgbs, masks.astype(bool))
+    assert np.array_equal(f2, flow) and np.array_equal(r2, rgb) and np.array_equal(m2.astype(np.uint8), mask)
+    # a single segment is its own result
+    f1, r1, m1 = pipeline.merge_segments(flows[:1], rgbs[:1], masks[:1])
+    assert np.array_equal(f1, flows[0]) and np.array_equal(m1, masks[0])
+
+
+def test_fit_bg_draw_order_and_window():
+    """three draws, in this order: uniform(1, 2), then the window's top row, then its left column (both ends included)"""
+    calls = []
+
+    class Rng:
+        def uniform(self, a, b):
+            calls.append(("uniform", a, b)); return 1.5
+        def randint(self, a, b):
+            calls.append(("randint", a, b)); return b            # the far end is a legal position
+
+    bg = np.zeros((10, 20, 3), np.uint8)
+    bg[:, :, 0] = 200                                          # constant colour: resizing keeps it
+    im = np.zeros((30, 30, 3), np.uint8)
+    out = pipeline.fit_bg(bg, im, rng=Rng())
+    assert calls == [("uniform", 1, 2), ("randint", 0, 45 - 30), ("randint", 0, 90 - 30)]
+    assert out.shape == (30, 30, 3) and (out[..., 0] == 200).all() and (out[..., 1:] == 0).all()
+
+
+def test_add_bg_selects_by_mask_value():
+    im = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    bg = im + 100
+    mk = np.asarray([[0, 255, 0], [7, 0, 255]], np.uint8)
+    out = pipeline.add_bg(im, mk, bg)                          # bgval = 0: mask 0 -> background
+    assert out.dtype == np.uint8 and np.array_equal(out[mk == 0], bg[mk == 0]) and np.array_equal(out[mk != 0], im[mk != 0])
+    out = pipeline.add_bg(im, mk, bg, bgval=255)
+    assert np.array_equal(out[mk == 255], bg[mk == 255]) and np.array_equal(out[mk != 255], im[mk != 255])
+    with pytest.raises(AssertionError):
+        pipeline.add_bg(im, mk[:, :2], bg)
+    with pytest.raises(AssertionError):
+        pipeline.add_bg(im, mk, bg[:, :2])
+
+
+def test_scale_rotate_portrait_transpose_and_nearest_mask(tmp_path):
+    """portrait -> landscape is a transpose (pixel (x, y) comes from (y, x)); the label mask is resized with nearest
+    neighbour (no new label values) and cut by the same box as the image"""
+    rgb = np.random.default_rng(3).integers(0, 256, (50, 20, 3), dtype=np.uint8)       # h = 50 > w = 20
+    lab = np.zeros((50, 20), np.uint8); lab[10:30, 5:15] = 3; lab[35:45, 2:8] = 9
+    Image.fromarray(rgb).save(tmp_path / "p.png"); Image.fromarray(lab).save(tmp_path / "pm.png")
+    changed, im, mk = pipeline.scale_rotate(str(tmp_path / "p.png"), str(tmp_path / "pm.png"))
+    assert changed and im.size == (50, 20)
+    assert np.array_equal(np.asarray(im), rgb.transpose(1, 0, 2)) and np.array_equal(np.asarray(mk), lab.T)
+    changed, im, mk = pipeline.scale_rotate(str(tmp_path / "p.png"), str(tmp_path / "pm.png"), size=(40, 30))
+    new, box = pipeline.resize_crop_geometry((50, 20), (40, 30))                        # (100, 40), (30, 5, 70, 35)
+    assert new == (100, 40) and box == (30, 5, 70, 35) and im.size == (40, 30) and mk.size == (40, 30)
+    assert set(np.unique(np.asarray(mk))) <= {0, 3, 9}
+    # nearest neighbour at scale 2: output pixel (x, y) of the resized mask is source pixel (x // 2, y // 2)
+    big = np.repeat(np.repeat(lab.T, 2, axis=0), 2, axis=1)
+    assert np.array_equal(np.asarray(mk), big[5:35, 30:70])
+    # a PNG pair that already has the target size is left alone
+    Image.fromarray(rgb.transpose(1, 0, 2)).save(tmp_path / "l.png"); Image.fromarray(lab.T).save(tmp_path / "lm.png")
+    changed, im, mk = pipeline.scale_rotate(str(tmp_path / "l.png"), str(tmp_path / "lm.png"), size=(50, 20))
+    assert not changed and np.array_equal(np.asarray(im), rgb.transpose(1, 0, 2))

@@ -17,7 +17,7 @@ for resident in (True, False):
     fs.solve(2, 1, 2, 60)
     outs.append([fs.results(b, want_rgb=False) for b in range(2)])
     if resident and os.environ.get("ARAPOPT_STAMPS") == "1":
-        out = np.zeros((512, 8), np.uint64)
+        out = np.zeros((512, 16), np.uint64)          # ArapFlow_SolverStamps copies RES_WGS x 16 u64
         st.lib.ArapFlow_SolverStamps(fs.h, out.ctypes.data)
         fl = out[:, 7]
         print("flags (1 granules fast, 2 z fast, 4 two-level sums, 8 first level plain):", {int(k): int((fl == k).sum()) for k in np.unique(fl)})
