@@ -24,6 +24,7 @@ enum : unsigned { F_E0 = 1u, F_E1 = 2u, F_E2 = 4u, F_E3 = 8u, F_FIT = 16u, F_ACT
 
 constexpr int TILE_X = 64;   // one wavefront = 64 consecutive x of one row: 256-B coalesced rows
 constexpr int TILE_Y = 4;    // 4 wavefronts per workgroup
+constexpr int RED_TICK_STRIDE = 64;   // u32 between two groups' arrival counters
 constexpr int NSHARD = 32;   // reduction groups (shards) per scalar: each shard is the order-fixed sum of one group of workgroups
 
 // One frame ("slot") of a batch: the five problem images of arap_plan.t:2-6 and the two weights.
@@ -70,7 +71,9 @@ struct PlanDev {
     const int* t64n;         // [batch]
     // order-fixed reductions of the kernel-per-phase paths (block_reduce_fixed below)
     unsigned long long* part; // [batch][maxblk][4] every workgroup's partial(s) of the running launch, as tagged granules
-    unsigned* tick;           // [batch][NSHARD][2] per reduction group: {arrivals of the running launch, launches so far}
+    unsigned* tick;           // [batch][NSHARD][RED_TICK_STRIDE] per reduction group: arrivals of the running launch, one
+                              // counter per 256 bytes (memory-side atomics on one line serialise: ~12 ns each)
+    unsigned* gen;            // [batch][NSHARD] launches the group has seen (read-mostly: stays in L2)
     int maxblk;               // workgroups per frame any launch of this plan may have
 };
 
@@ -182,39 +185,62 @@ __device__ __forceinline__ double wave_sum(double v)
 __device__ __forceinline__ unsigned red_tag(const PlanDev& pd, int b, unsigned lb)
 {
     // (may be read any time before the workgroup's own arrival: only the group's last arriver changes it)
-    return __hip_atomic_load(pd.tick + ((size_t)b * NSHARD + (lb % NSHARD)) * 2 + 1, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    return __hip_atomic_load(pd.gen + (size_t)b * NSHARD + (lb % NSHARD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
 }
 
+// The sum in two calls, so that a streaming kernel can put its own stores BETWEEN them: red_arrive (block-level sum,
+// partial out, ticket taken -- nothing is waited for) ... the kernel's stores ... red_finish (the ticket's value is
+// needed only here).  vmcnt completes in order: a ticket taken AFTER a wave's streaming stores comes back only when those
+// have drained, and the wave -- with it the workgroup's slot on the CU -- lives that long (measured at 1920x1080, mask == 0,
+// phase B: 31 us with the ticket in front of the stores, 61 us behind them).
+struct RedTicket {
+    unsigned ticket;       // the group's arrival count before this workgroup's (valid in wave 0, lane 0; not yet waited for)
+    unsigned tag, g, ng;
+};
+
 template <int NV>
-__device__ __forceinline__ void block_reduce_fixed(const PlanDev& pd, int b, unsigned lb, unsigned nlb, double v0,
-                                                   double v1, double* tgt0, double* tgt1, unsigned tag = 0u)
+__device__ __forceinline__ RedTicket red_arrive(const PlanDev& pd, int b, unsigned lb, unsigned nlb, double v0, double v1,
+                                                unsigned tag = 0u)
 {
     __shared__ double wsumF[2][16];
     const unsigned lin = threadIdx.y * blockDim.x + threadIdx.x, wave = lin >> 6, lane = lin & 63;
     const unsigned nw = (blockDim.x * blockDim.y + 63u) >> 6;
+    RedTicket rt;
+    rt.g = lb % NSHARD;
+    rt.ng = (nlb - rt.g + NSHARD - 1) / NSHARD;                // members of this group: g, g + NSHARD, ...
+    rt.ticket = 0u;
     if (tag == 0u && wave == 0) tag = red_tag(pd, b, lb);
+    rt.tag = tag;
     v0 = wave_sum(v0);
     if (NV > 1) v1 = wave_sum(v1);
     if (lane == 0) { wsumF[0][wave] = v0; if (NV > 1) wsumF[1][wave] = v1; }
     __syncthreads();
-    if (wave != 0) return;
+    if (wave != 0) return rt;
     double t0 = 0.0, t1 = 0.0;
     for (unsigned w = 0; w < nw; ++w) { t0 += wsumF[0][w]; if (NV > 1) t1 += wsumF[1][w]; }
-    const unsigned g = lb % NSHARD, ng = (nlb - g + NSHARD - 1) / NSHARD;      // members of this group: g, g + NSHARD, ...
-    unsigned* tk = pd.tick + ((size_t)b * NSHARD + g) * 2;
-    unsigned long long* const base = pd.part + (size_t)b * pd.maxblk * 4;
+    unsigned long long* const mine = pd.part + ((size_t)b * pd.maxblk + lb) * 4;
     if (lane < 2u * NV) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(lane < 2 ? t0 : t1);
         const unsigned hw = (lane & 1u) ? (unsigned)(bits >> 32) : (unsigned)bits;
-        __hip_atomic_store(base + (size_t)lb * 4 + lane, ((unsigned long long)tag << 32) | hw, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + lane, ((unsigned long long)tag << 32) | hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    unsigned ticket = 0u;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (lane == 0)
+        rt.ticket = __hip_atomic_fetch_add(pd.tick + ((size_t)b * NSHARD + rt.g) * RED_TICK_STRIDE, 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+    return rt;
+}
+
+template <int NV>
+__device__ __forceinline__ void red_finish(const PlanDev& pd, int b, const RedTicket& rt, double* tgt0, double* tgt1)
+{
+    const unsigned lin = threadIdx.y * blockDim.x + threadIdx.x, wave = lin >> 6, lane = lin & 63;
+    if (wave != 0) return;
+    const unsigned ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)rt.ticket);
+    const unsigned g = rt.g, ng = rt.ng, tag = rt.tag;
     if (ticket + 1u != ng) return;
     // ---- the group's last arriver ----
+    unsigned* tk = pd.tick + ((size_t)b * NSHARD + g) * RED_TICK_STRIDE;
+    const unsigned long long* const base = pd.part + (size_t)b * pd.maxblk * 4;
     double a0 = 0.0, a1 = 0.0;
     bool ok = false;
     for (unsigned spins = 0; spins < (1u << 16) && !ok; ++spins) {
@@ -243,8 +269,16 @@ __device__ __forceinline__ void block_reduce_fixed(const PlanDev& pd, int b, uns
     }
     if (lane == 0) {           // ready for the next launch (seen there after the kernel boundary)
         __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(tk + 1, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pd.gen + (size_t)b * NSHARD + g, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_fixed(const PlanDev& pd, int b, unsigned lb, unsigned nlb, double v0,
+                                                   double v1, double* tgt0, double* tgt1, unsigned tag = 0u)
+{
+    const RedTicket rt = red_arrive<NV>(pd, b, lb, nlb, v0, v1, tag);
+    red_finish<NV>(pd, b, rt, tgt0, tgt1);
 }
 
 // sum of the NSHARD shards of one scalar, by every wavefront for itself (lanes >= NSHARD add 0)

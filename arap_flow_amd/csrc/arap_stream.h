@@ -256,8 +256,14 @@ __global__ __launch_bounds__(256) void k_pcg_a_march(PlanDev pd, int l, int stri
     __syncthreads();
     const float wr2 = sl.wr * sl.wr, wf2 = sl.wf * sl.wf;
     double d = 0.0;
+    // A block's Ap is stored one block late, the last block's after the workgroup's ticket has been taken (red_arrive:
+    // a ticket behind streaming stores comes back only when they have drained)
+    float2 pendO = make_float2(0.f, 0.f);
+    float pendA = 0.f;
+    int pendI = -1;
     for (int k = 0; k < nblk; ++k) {
         const Stage nx = issue(k + 2);                            // (block nblk: the halo row below; beyond: nothing)
+        if (pendI >= 0) { pd.ApO[gb + pendI] = pendO; pd.ApA[gb + pendI] = pendA; pendI = -1; }
         const int y = ybase + 4 * k + w;
         if (active(k) && x < W && y < H) {
             const int r = ((k & 3) << 2) | w, ru = (r + RROWS - 1) & (RROWS - 1), rd = (r + 1) & (RROWS - 1);
@@ -291,16 +297,18 @@ __global__ __launch_bounds__(256) void k_pcg_a_march(PlanDev pd, int l, int stri
                     ax = fmaf(wf2, pO.x, ax);
                     ay = fmaf(wf2, pO.y, ay);
                 }
-                const int i = x + W * y;
-                pd.ApO[gb + i] = make_float2(ax, ay);
-                pd.ApA[gb + i] = aa;
+                pendI = x + W * y;
+                pendO = make_float2(ax, ay);
+                pendA = aa;
                 d += (double)dot3(pO.x, pO.y, pA, ax, ay, aa);
             }
         }
         finish(k + 2, nx);
         __syncthreads();
     }
-    block_reduce_fixed<1>(pd, b, lb, nlb, d, 0.0, sigma_l, nullptr, rtag);
+    const RedTicket rt = red_arrive<1>(pd, b, lb, nlb, d, 0.0, rtag);
+    if (pendI >= 0) { pd.ApO[gb + pendI] = pendO; pd.ApA[gb + pendI] = pendA; }
+    red_finish<1>(pd, b, rt, sigma_l, nullptr);
 }
 
 // Phase B (k_pcg_b4's update, four consecutive vertices per lane, 16-byte accesses) without the z and preO reads.
@@ -335,12 +343,13 @@ __global__ __launch_bounds__(256) void k_pcg_b4_lean(PlanDev pd, int l)
     __syncthreads();
     double d = 0.0;
     const unsigned fw = q < nq ? ((const unsigned*)(pd.flags + gb))[q] : 0u;      // 4 flag bytes
-    if (fw & 0x20202020u) {
-        float4* dO4 = (float4*)(pd.deltaO + gb); float4* rO4 = (float4*)(pd.rO + gb); float4* zO4 = (float4*)(pd.zO + gb);
-        float4* dA4 = (float4*)(pd.deltaA + gb); float4* rA4 = (float4*)(pd.rA + gb); float4* zA4 = (float4*)(pd.zA + gb);
+    const bool any_active = (fw & 0x20202020u) != 0u;
+    float4* dO4 = (float4*)(pd.deltaO + gb); float4* rO4 = (float4*)(pd.rO + gb); float4* zO4 = (float4*)(pd.zO + gb);
+    float4* dA4 = (float4*)(pd.deltaA + gb); float4* rA4 = (float4*)(pd.rA + gb); float4* zA4 = (float4*)(pd.zA + gb);
+    float po[8], apo[8], dl[8], r[8], z[8], pa[4], apa[4], ma[4], dla[4], ra[4], za[4];
+    if (any_active) {
         const float4* ApO4 = (const float4*)(pd.ApO + gb);
         const float4* ApA4 = (const float4*)(pd.ApA + gb); const float4* mA4 = (const float4*)(pd.preA + gb);
-        float po[8], apo[8], dl[8], r[8], z[8], pa[4], apa[4], ma[4], dla[4], ra[4], za[4];
         *(float4*)&po[0] = pO4[2 * q]; *(float4*)&po[4] = pO4[2 * q + 1];
         *(float4*)&apo[0] = ApO4[2 * q]; *(float4*)&apo[4] = ApO4[2 * q + 1];
         *(float4*)&dl[0] = dO4[2 * q]; *(float4*)&dl[4] = dO4[2 * q + 1];
@@ -368,12 +377,17 @@ __global__ __launch_bounds__(256) void k_pcg_b4_lean(PlanDev pd, int l)
             za[k] = ma[k] * ra[k];
             d += (double)dot3(z[2 * k], z[2 * k + 1], za[k], r[2 * k], r[2 * k + 1], ra[k]);
         }
+    }
+    // the workgroup's share of rho_{l+1} goes out, and its ticket is taken, BEFORE the nine streaming stores below (the
+    // ticket's return would otherwise wait for them to drain: arap_device.h, red_arrive)
+    const RedTicket rt = red_arrive<1>(pd, b, blockIdx.x, gridDim.x, d, 0.0, rtag);
+    if (any_active) {
         dO4[2 * q] = *(float4*)&dl[0]; dO4[2 * q + 1] = *(float4*)&dl[4];
         rO4[2 * q] = *(float4*)&r[0]; rO4[2 * q + 1] = *(float4*)&r[4];
         zO4[2 * q] = *(float4*)&z[0]; zO4[2 * q + 1] = *(float4*)&z[4];
         dA4[q] = *(float4*)dla; rA4[q] = *(float4*)ra; zA4[q] = *(float4*)za;
     }
-    block_reduce_fixed<1>(pd, b, blockIdx.x, gridDim.x, d, 0.0, pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD, nullptr, rtag);
+    red_finish<1>(pd, b, rt, pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD, nullptr);
 }
 
 }  // namespace arap

@@ -194,8 +194,9 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     // kernel of this plan -- every tile shape is at least 16 wide and 4 high -- and the groups' tickets
     pd.maxblk = ((W + 15) / 16) * ((H + 3) / 4) + 16;
     const size_t szp = align_up((size_t)batch * pd.maxblk * 4 * sizeof(unsigned long long), 256);
-    const size_t szk = align_up((size_t)batch * NSHARD * 2 * sizeof(unsigned), 256);
-    const size_t total = 8 * sz2 + 7 * sz1 + szf + szt + szs + szp + szk;
+    const size_t szk = align_up((size_t)batch * NSHARD * RED_TICK_STRIDE * sizeof(unsigned), 256);
+    const size_t szg = align_up((size_t)batch * NSHARD * sizeof(unsigned), 256);
+    const size_t total = 8 * sz2 + 7 * sz1 + szf + szt + szs + szp + szk + szg;
     HC(hipMalloc(&p->block, total));
     HC(hipMemsetAsync(p->block, 0, total, st->stream));
     char* c = (char*)p->block;
@@ -211,6 +212,7 @@ static Opt_Plan* plan_create(Opt_State* st, int W, int H, int batch)
     pd.slots = (Slot*)take(szs);
     pd.part = (unsigned long long*)take(szp);
     pd.tick = (unsigned*)take(szk);
+    pd.gen = (unsigned*)take(szg);
     pd.red = nullptr; pd.costred = nullptr; pd.nslots = 0; pd.ncost = 0;
     p->hslots.assign(batch, Slot{});
     p->h_ntiles.assign(batch, 0);
