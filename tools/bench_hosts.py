@@ -6,7 +6,14 @@
      precomputed match files) with the C++ driver as a persistent --serve worker: wall time from process start to
      exit, time since the GPU worker was ready, batch sizes handed to the GPU (OUT/arap_stats.json);
   2. the C++ driver and its Python twin on a list file of the same frames (process start to exit).
-One JSON record on stdout (and into --out): what profiles/r02_hosts*.json hold."""
+One JSON record on stdout (and into --out): what profiles/r02_hosts*.json hold.
+
+    python tools/bench_hosts.py 512 --standin 8 [--jobs J]          (no GPU needed)
+
+Host capacity of a node: `para_gen.py --gpu 0 1 .. 7` with a STAND-IN in place of the GPU worker -- a process per GPU id
+that speaks the --serve protocol and does the worker's file work (decode the two PNGs of a line, write a .flo and two
+PNGs) but no solve.  What is measured is whether one host can prepare, hand out and post-process pairs fast enough for
+8 GPUs at 28 pairs/s each (224 pairs/s): pairs/s, the CPUs this process may use, --jobs."""
 import argparse
 import json
 import os
@@ -43,9 +50,33 @@ def make_tree(d, pairs, W, H, K):
     return inp, mdir
 
 
+STANDIN = r'''
+import sys
+import numpy as np
+from PIL import Image
+sys.path.insert(0, %r)
+from arap_flow_amd import flo as F
+# stand-in for `arap_deform --serve` on one GPU id: the worker's file work, no solve (tools/bench_hosts.py --standin)
+print("Ready", flush=True)
+for line in sys.stdin:
+    rgb, msk, cst, flo, wrgb, wmsk = line.split()
+    im = np.array(Image.open(rgb).convert("RGB"))
+    m = np.array(Image.open(msk).convert("RGB"))[..., 0]
+    open(cst).read()
+    F.flow_write(flo, np.zeros(m.shape + (2,), np.float32))
+    Image.fromarray(im).save(wrgb)
+    Image.fromarray(m == 0).save(wmsk)
+    print("Batch 1", flush=True)
+    print("Done " + flo, flush=True)
+'''
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("pairs", type=int, nargs="?", default=128)
+    ap.add_argument("--standin", type=int, default=0, metavar="NGPU",
+                    help="host capacity run: NGPU stand-in workers (no GPU), see the module docstring")
+    ap.add_argument("--jobs", type=int, default=0)
     ap.add_argument("--multseg", action="store_true")
     ap.add_argument("--size", type=int, nargs=2, default=[854, 480])
     ap.add_argument("--out", default=None)
@@ -61,6 +92,25 @@ def main():
         out = os.path.join(d, "out")
         cmd = [sys.executable, os.path.join(ROOT, "para_gen.py"), "--input", inp, "--output", out, "--gpu", "0",
                "--matches", mdir] + (["--multseg"] if a.multseg else [])
+        if a.standin:
+            fake = os.path.join(d, "standin_worker.py")
+            open(fake, "w").write(STANDIN % ROOT)
+            cmd = [sys.executable, os.path.join(ROOT, "para_gen.py"), "--input", inp, "--output", out, "--gpu"] + \
+                  [str(g) for g in range(a.standin)] + ["--matches", mdir, "--worker", "serve", "--arap_bin",
+                                                        "%s %s" % (sys.executable, fake)] + (["--multseg"] if a.multseg else [])
+            a.skip_list_mode = True
+            try:
+                rec["cpus_usable"] = len(os.sched_getaffinity(0))
+            except AttributeError:
+                rec["cpus_usable"] = os.cpu_count()
+            try:                                                   # cgroup v2 CPU quota (a 1-GPU box: 16 of the host's cores)
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                rec["cpu_quota"] = None if quota == "max" else float(quota) / float(period)
+            except (OSError, ValueError):
+                rec["cpu_quota"] = None
+            rec["standin_workers"] = a.standin
+        if a.jobs:
+            cmd += ["--jobs", str(a.jobs)]
         env = {k: v for k, v in os.environ.items() if k != "ARAP_PLAN"}
         t = time.time()
         r = subprocess.run(cmd, env=env, cwd=d, capture_output=True, text=True)
@@ -74,7 +124,9 @@ def main():
                            "frames_per_s_wall": st["frames"] / dt,
                            "frames_per_s_since_worker_ready": st["frames"] / st["seconds_since_workers_ready"]
                            if st.get("seconds_since_workers_ready") else None,
-                           "mean_batch": st["mean_batch"], "batches": st["batches"], "jobs": st["jobs"],
+                           "mean_batch": st["mean_batch"],
+                           "batches": st["batches"] if not a.standin else "1 each (the stand-in reports every line)",
+                           "jobs": st["jobs"],
                            "narap": st["narap"], "worker": st["worker"]}
         if not a.skip_list_mode:
             n = min(a.pairs, 64)
