@@ -106,7 +106,10 @@ constexpr unsigned RES_SPIN_LIMIT = 1u << 18;
 #define RES_GRAN_STRIDE 2     // u64 between two workgroups' granule pairs: 2 = packed (8 pairs per 128-byte line), 16 = a line each
 #endif
 constexpr int RES_GS = RES_GRAN_STRIDE;
-constexpr int RES_GRAN_L1 = 2 * RES_WGS * RES_GS;
+// (a group of several XCD runs addresses its runs in blocks of 64 workgroups, whatever the size of its last run: the
+//  host reserves whole blocks, arapopt.hip: resident_deal -- at most 7 x 128 such units in a launch, hence 2 x RES_WGS)
+constexpr int RES_GRAN_UNITS = 2 * RES_WGS;
+constexpr int RES_GRAN_L1 = 2 * RES_GRAN_UNITS * RES_GS;
 constexpr int RES_GRAN2_STRIDE = 16;            // u64 per second-level granule pair: one 128-byte line per XCD run
 constexpr int RES_GRAN2_GROUP = 2 * 8 * RES_GRAN2_STRIDE;
 // third region: a write-through copy of every workgroup's granules, same offsets as the first (group_sum_x)
@@ -347,7 +350,8 @@ __device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigne
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
-        const int sub = rank >> 6, srank = rank & 63, nsub = wgs >> 6;
+        // (the last run may be shorter than 64: a solve's home XCD plus a piece elsewhere, arapopt.hip: resident_deal)
+        const int sub = rank >> 6, srank = rank & 63, nsub = (wgs + 63) >> 6;
         unsigned long long* bufl = gran_group + (size_t)sub * (128 * RES_GS) + (size_t)(epoch & 1u) * (64 * RES_GS);
         unsigned long long* bufx = granx_group + (size_t)(epoch & 1u) * wgs * RES_GS;      // [wgs] pairs, rank order
         part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
@@ -372,6 +376,7 @@ __device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigne
             v = 0.0;
             bool mine_ok = true;
             for (int r = 0; r < nsub; ++r) {                          // rank r * 64 + lane: own run locally, others remotely
+                if (r * 64 + lane >= wgs) break;                      // (the last run may be short)
                 const unsigned long long* src = r == sub ? bufl + RES_GS * lane : bufx + RES_GS * (r * 64 + lane);
                 const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -674,8 +679,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         // group's sums are gathered in two levels (group_sum_h); the first level uses plain granule stores if the 64
         // workgroups of this XCD run really share an XCD.  The epoch-1 granules still hold every workgroup's id (a
         // granule that a faster workgroup has already reused carries another tag and counts as "elsewhere").
-        hier = !fast && wgs > 64 && (wgs & 63) == 0;
-        hierx = hier && (wgs >> 6) <= rd.flat_runs;
+        // (a group of two runs always sums in one hop: its second run may be a short piece, and the second-level granules
+        //  of group_sum_h are addressed by whole aligned bins)
+        hier = !fast && wgs > 64;
+        hierx = hier && (((wgs + 63) >> 6) <= 2 || ((wgs + 63) >> 6) <= rd.flat_runs);
         if (!fast && rd.allow_fast && alive) {
             if (wave == 0) {
                 const unsigned long long* buf = gran_group + (size_t)1 * wgs * RES_GS;     // parity of epoch 1

@@ -444,26 +444,32 @@ static bool plan_resident_eligible(const Opt_Plan* p)
 // Deal the solves of the current batch to resident launches and their 512 workgroups (ResWg tables).
 // A launch is 8 bins of 64 workgroups: the workgroups that land on one XCD (blockIdx & 7 equal, local index
 // blockIdx >> 3).  A solve of nt active tiles needs ceil(nt / 9) workgroups.
-//  * A solve that fits one bin shares it with others: the narrow solves are bin-packed into as few launches as
-//    first-fit-decreasing needs, spread evenly over the free bins (least-loaded first), and every group is then
+//  * NARROW (needs <= 64): shares a bin with others: the narrow solves are bin-packed into as few launches as
+//    first-fit-decreasing needs, spread evenly over the shared bins (least-loaded first), and every group is then
 //    widened to use its bin's spare workgroups (fewer tiles per workgroup = shorter phases).  Groups of one bin take
 //    consecutive local indices, so the two workgroups of a CU (j, j + 32) usually serve different solves.
-//  * A wider solve takes 2, 4 or 8 whole bins, aligned to its width.  Every bin holds a run of 64 consecutive ranks:
-//    tiles are dealt in list (row-major) order, so nearly all of a workgroup's halo neighbours share its XCD; only
-//    the workgroups next to a run boundary publish z write-through and the group's sums are gathered in two levels
-//    (arap_resident.h).
+//  * MEDIUM (65 .. 128: the 1920x1080 --multseg segments, ~716 tiles = 80 workgroups): a whole bin as HOME for ranks
+//    0 .. 63 plus a PIECE of need - 64 workgroups (ranks 64 ..) in a bin it shares with other pieces and narrow solves,
+//    widened like those.  Six such solves fit a launch (six homes, two shared bins) where whole pairs of bins held four.
+//    Tiles are dealt in list (row-major) order, so nearly all of a workgroup's halo neighbours share its XCD; the
+//    group's sums are gathered in one hop (arap_resident.h: group_sum_x, runs of 64 ranks).
+//  * WIDE (> 128): 4 or 8 whole bins, aligned to the width; every bin holds a run of 64 consecutive ranks; sums in two
+//    levels (group_sum_h).
+// Placement is for speed only: the kernel checks at run time which runs really share an XCD.
 // Returns the number of launches; fills `map` ([launches][RES_WGS]) and `inflight_out` when given.
 static int resident_deal(const int* ntiles, int nb, std::vector<ResWg>* map_out, int* inflight_out)
 {
     const int XW = RES_WGS / 8;                                  // workgroups per XCD
-    std::vector<int> need(nb), width(nb);
+    enum { NARROW = 0, MEDIUM = 1, WIDE = 2 };
+    std::vector<int> need(nb), width(nb), kind(nb);
     int mx = 1;
     for (int b = 0; b < nb; ++b) {
         need[b] = (ntiles[b] + RES_TILES_PER_WG - 1) / RES_TILES_PER_WG;
         if (need[b] < 1) need[b] = 1;
         mx = need[b] > mx ? need[b] : mx;
-        width[b] = 1;                                            // bins taken: 1 (shared) or 2, 4, 8 (whole)
-        while (width[b] * XW < need[b]) width[b] *= 2;
+        kind[b] = need[b] <= XW ? NARROW : (need[b] <= 2 * XW ? MEDIUM : WIDE);
+        width[b] = 1;                                            // whole bins a WIDE solve takes: 4 or 8
+        if (kind[b] == WIDE) { width[b] = 4; while (width[b] * XW < need[b]) width[b] *= 2; }
     }
     std::vector<ResWg> map;
     int nsets = 0, inflight = 0;
@@ -491,14 +497,15 @@ static int resident_deal(const int* ntiles, int nb, std::vector<ResWg>* map_out,
         std::vector<int> order(nb);
         for (int b = 0; b < nb; ++b) order[b] = b;
         std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
-            return width[a] != width[c] ? width[a] > width[c] : need[a] > need[c];
+            return kind[a] != kind[c] ? kind[a] > kind[c] : (width[a] != width[c] ? width[a] > width[c] : need[a] > need[c]);
         });
-        // bin state over all launches: owner >= 0: a wide solve holds the whole bin; owner == -1: shared / free
+        // bin state over all launches.  owner >= 0: a wide solve, or a medium solve's home, holds the whole bin;
+        // owner == -1: shared / free (load = workgroups spoken for)
         std::vector<int> owner, load;
         auto add_launch = [&]() { owner.insert(owner.end(), 8, -1); load.insert(load.end(), 8, 0); };
         // (1) wide solves: first launch with `width` aligned bins that nothing has touched yet
         for (int b : order) {
-            if (width[b] == 1) continue;
+            if (kind[b] != WIDE) continue;
             size_t at = owner.size();
             for (size_t k = 0; k + width[b] <= owner.size() && at == owner.size(); k += width[b]) {
                 bool free_run = true;
@@ -508,64 +515,104 @@ static int resident_deal(const int* ntiles, int nb, std::vector<ResWg>* map_out,
             if (at == owner.size()) add_launch();                // 8 is a multiple of every width: `at` is aligned
             for (int q = 0; q < width[b]; ++q) { owner[at + q] = b; load[at + q] = XW; }
         }
-        // (2) narrow solves: number of launches by first fit decreasing over the shared bins ...
-        std::vector<int> ff = load;
+        // (2) medium solves: a free bin as home, the piece first-fit into a bin of the same launch that pieces already
+        //     share (so that free bins stay available as homes), else into a free one
+        std::vector<int> home(nb, -1);                           // medium: its home bin (global index)
+        std::vector<int> ffbin(nb, -1);                          // first-fit bin of every shared item (piece or narrow solve)
+        auto item_size = [&](int b) { return kind[b] == MEDIUM ? need[b] - XW : need[b]; };
         for (int b : order) {
-            if (width[b] != 1) continue;
+            if (kind[b] != MEDIUM) continue;
+            const int piece = item_size(b);
+            int hb = -1, pb = -1;
+            for (size_t L = 0; L * 8 < owner.size() && hb < 0; ++L) {
+                int h = -1, pshared = -1, pfree = -1;
+                for (int x = 0; x < 8; ++x) {
+                    const size_t k = L * 8 + x;
+                    if (owner[k] >= 0) continue;
+                    if (load[k] == 0) { if (h < 0) h = (int)k; else if (pfree < 0) pfree = (int)k; }
+                    else if (pshared < 0 && load[k] + piece <= XW) pshared = (int)k;
+                }
+                const int pk = pshared >= 0 ? pshared : pfree;
+                if (h >= 0 && pk >= 0) { hb = h; pb = pk; }
+            }
+            if (hb < 0) { hb = (int)owner.size(); pb = hb + 1; add_launch(); }
+            owner[hb] = b; load[hb] = XW; home[b] = hb;
+            load[pb] += piece; ffbin[b] = pb;
+        }
+        // (3) narrow solves: number of launches by first fit decreasing over the shared bins ...
+        for (int b : order) {
+            if (kind[b] != NARROW) continue;
             size_t k = 0;
-            while (k < ff.size() && ff[k] + need[b] > XW) ++k;
-            if (k == ff.size()) { add_launch(); ff.insert(ff.end(), 8, 0); }
-            ff[k] += need[b];
+            while (k < owner.size() && (owner[k] >= 0 || load[k] + need[b] > XW)) ++k;
+            if (k == owner.size()) add_launch();
+            load[k] += need[b]; ffbin[b] = (int)k;
         }
         nsets = (int)owner.size() / 8;
-        // ... then spread: least-loaded shared bin that still fits; keep the first-fit deal if that ever fails
-        std::vector<std::vector<int>> bins(owner.size());
-        std::vector<int> l2 = load;
+        // ... then spread: pieces over the shared bins of their launch, narrow solves over all shared bins, least-loaded
+        // bin that still fits first; keep the first-fit deal if that ever fails
+        std::vector<int> bin_of(nb, -1), l2(owner.size(), 0);
         bool ok = true;
-        for (int b : order) {
-            if (width[b] != 1) continue;
-            int best = -1;
-            for (size_t k = 0; k < l2.size(); ++k)
-                if (owner[k] < 0 && l2[k] + need[b] <= XW && (best < 0 || l2[k] < l2[best])) best = (int)k;
-            if (best < 0) { ok = false; break; }
-            l2[best] += need[b];
-            bins[best].push_back(b);
-        }
-        if (!ok) {
-            for (auto& v : bins) v.clear();
-            l2 = load;
+        for (int pass = 0; pass < 2 && ok; ++pass)
             for (int b : order) {
-                if (width[b] != 1) continue;
-                size_t k = 0;
-                while (l2[k] + need[b] > XW) ++k;                // a wide solve's bins are full: skipped
-                l2[k] += need[b];
-                bins[k].push_back(b);
+                if (kind[b] == WIDE || (pass == 0) != (kind[b] == MEDIUM)) continue;
+                const int sz = item_size(b);
+                const size_t lo = kind[b] == MEDIUM ? (size_t)(home[b] / 8) * 8 : 0;
+                const size_t hi = kind[b] == MEDIUM ? lo + 8 : owner.size();
+                int best = -1;
+                for (size_t k = lo; k < hi; ++k)
+                    if (owner[k] < 0 && l2[k] + sz <= XW && (best < 0 || l2[k] < l2[best])) best = (int)k;
+                if (best < 0) { ok = false; break; }
+                l2[best] += sz;
+                bin_of[b] = best;
             }
+        if (!ok) {
+            bin_of = ffbin;
+            std::fill(l2.begin(), l2.end(), 0);
+            for (int b = 0; b < nb; ++b)
+                if (kind[b] != WIDE) l2[bin_of[b]] += item_size(b);
+        }
+        // workgroups of every group: a shared item gets its bin's spare workgroups in proportion (>= its need)
+        std::vector<int> wgs_of(nb, 0), part_w(nb, 0);
+        for (int b = 0; b < nb; ++b) {
+            if (kind[b] == WIDE) { wgs_of[b] = width[b] * XW; continue; }
+            part_w[b] = XW * item_size(b) / l2[bin_of[b]];       // >= the item's size; a bin's parts sum to <= 64
+            wgs_of[b] = kind[b] == MEDIUM ? XW + part_w[b] : part_w[b];
         }
         map.assign((size_t)nsets * RES_WGS, idle);
+        std::vector<int> gran_of(nb, -1);
         for (int set = 0; set < nsets; ++set) {
-            int ordinal = 0, count = 0;                          // workgroups / solves dealt in this launch
+            // granule space per group, in units of workgroups: a group of several runs addresses its runs in blocks of 64
+            int ordinal = 0, count = 0;
+            auto take_gran = [&](int b) {
+                if (gran_of[b] >= 0) return;
+                gran_of[b] = 2 * RES_GS * ordinal;
+                ordinal += wgs_of[b] > XW ? ((wgs_of[b] + XW - 1) / XW) * XW : wgs_of[b];
+                ++count;
+            };
             for (int x = 0; x < 8; ++x) {
                 const size_t k = (size_t)set * 8 + x;
                 if (owner[k] >= 0) {
-                    const int b = owner[k], wgs = width[b] * XW;
+                    const int b = owner[k];
+                    take_gran(b);
+                    if (kind[b] == MEDIUM) {                     // home: ranks 0 .. 63
+                        for (int j = 0; j < XW; ++j)
+                            map[(size_t)set * RES_WGS + (size_t)j * 8 + x] = ResWg{b, j, wgs_of[b], gran_of[b]};
+                        continue;
+                    }
                     const bool first = x == 0 || owner[k - 1] != b;
                     if (!first) continue;                        // dealt with its first bin
                     for (int q = 0; q < width[b]; ++q)
                         for (int j = 0; j < XW; ++j)
-                            map[(size_t)set * RES_WGS + (size_t)j * 8 + x + q] = ResWg{b, q * XW + j, wgs, 2 * RES_GS * ordinal};
-                    ordinal += wgs;
-                    ++count;
+                            map[(size_t)set * RES_WGS + (size_t)j * 8 + x + q] = ResWg{b, q * XW + j, wgs_of[b], gran_of[b]};
                     continue;
                 }
-                const std::vector<int>& v = bins[k];
                 int j = 0;
-                for (int b : v) {
-                    const int wgs = XW * need[b] / l2[k];        // >= need[b]; the widths of a bin sum to <= 64
-                    for (int r = 0; r < wgs; ++r, ++j)
-                        map[(size_t)set * RES_WGS + (size_t)j * 8 + x] = ResWg{b, r, wgs, 2 * RES_GS * ordinal};
-                    ordinal += wgs;
-                    ++count;
+                for (int b : order) {                            // the bin's items, largest first
+                    if (kind[b] == WIDE || bin_of[b] != (int)k) continue;
+                    take_gran(b);
+                    const int r0 = kind[b] == MEDIUM ? XW : 0;
+                    for (int r = 0; r < part_w[b]; ++r, ++j)
+                        map[(size_t)set * RES_WGS + (size_t)j * 8 + x] = ResWg{b, r0 + r, wgs_of[b], gran_of[b]};
                 }
             }
             inflight = count > inflight ? count : inflight;

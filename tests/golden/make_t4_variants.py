@@ -41,7 +41,7 @@ VARIANTS = [
 ]
 
 
-def frame_schedule(mask_red, cons, A0, numIter=19, nIter=8, lIter=400):
+def frame_schedule(mask_red, cons, A0, numIter=19, nIter=8, lIter=400, trig=1):
     """the arap_deform schedule (CombinedSolverBase.h:99-120) from Python over oracle.solve, product arithmetic, with
     a chosen initial Angle image (oracle.frame itself always starts from Angle = 0, CombinedSolver.h:207-221)"""
     H, W = mask_red.shape
@@ -54,26 +54,29 @@ def frame_schedule(mask_red, cons, A0, numIter=19, nIter=8, lIter=400):
     costs = None
     for i in range(numIter):
         Cn = orc.constraint_image(mask_red, allc, np.float32(i + 1) / np.float32(numIter))
-        O, A, costs = orc.solve(O, A, U, Cn, M, wf, wr, nIter, lIter, dtype=np.float32, mode=1, trig=1)
+        O, A, costs = orc.solve(O, A, U, Cn, M, wf, wr, nIter, lIter, dtype=np.float32, mode=1, trig=trig)
     return O, A, costs
 
 
-def perturbed_starts(cat, flows_ref, nseeds=6, amp=1e-6):
-    """How far does a perturbation far below anything physical move the answer?  Same arithmetic as the product, the
-    initial Angle image N(0, amp^2) rad instead of exactly 0 (amp = 1e-6 rad: 1e-4 px over a 100 px lever)."""
+def perturbed_starts(cat, flows_ref, nseeds=6, amp=1e-6, trig=1, have=None):
+    """How far does a perturbation far below anything physical move the answer?  Same arithmetic as the product (or, with
+    trig = 0 and the no-FMA build selected by the caller, the variant f32_sum64_libm_nofma), the initial Angle image
+    N(0, amp^2) rad instead of exactly 0 (amp = 1e-6 rad: 1e-4 px over a 100 px lever).  `have`: rows already made."""
     gold = cat["golden_flow"]
     act = cat["mask_red"] == 0
     H, W = act.shape
     # sanity: zero perturbation reproduces oracle.frame bit for bit
-    O0, A0, c0 = frame_schedule(cat["mask_red"], cat["constraints"], np.zeros((H, W), np.float32), numIter=2, nIter=2, lIter=30)
-    Of, Af, cf = orc.frame(cat["mask_red"], cat["constraints"], numIter=2, nIterations=2, lIterations=30, dtype=np.float32, mode=1, trig=1)
+    O0, A0, c0 = frame_schedule(cat["mask_red"], cat["constraints"], np.zeros((H, W), np.float32), numIter=2, nIter=2, lIter=30, trig=trig)
+    Of, Af, cf = orc.frame(cat["mask_red"], cat["constraints"], numIter=2, nIterations=2, lIterations=30, dtype=np.float32, mode=1, trig=trig)
     assert np.array_equal(O0, Of) and np.array_equal(A0, Af)
-    rows = {}
+    rows = dict(have or {})
     for sd in range(nseeds):
+        if "seed%d" % sd in rows:
+            continue
         rng = np.random.default_rng(4242 + sd)
         A_init = (rng.normal(size=(H, W)) * amp).astype(np.float32) * act
         t = time.time()
-        O, A, costs = frame_schedule(cat["mask_red"], cat["constraints"], A_init)
+        O, A, costs = frame_schedule(cat["mask_red"], cat["constraints"], A_init, trig=trig)
         flow = orc.flow_from_offset(O)
         err = np.linalg.norm(flow - gold, axis=-1)[act]
         rows["seed%d" % sd] = {"initial_angle_sigma_rad": amp, "final_cost": float(costs[-1]),
@@ -87,7 +90,34 @@ def perturbed_starts(cat, flows_ref, nseeds=6, amp=1e-6):
     return rows
 
 
+def more_perturbed(n_product=20, n_nofma=12):
+    """--perturbed-only: keep the variant rows of the committed table and (re)make only the perturbed starts -- n_product
+    seeds of the product's arithmetic and n_nofma seeds of f32_sum64_libm_nofma (a second arithmetic, so that the
+    empirical band is not the scatter of one rounding recipe alone).  ~1 minute per run on 8 cores."""
+    cat = helpers.load_cat512(HERE)
+    path = os.path.join(HERE, "t4_variants.json")
+    tab = json.load(open(path))
+    act = cat["mask_red"] == 0
+    orc.use_variant(None)
+    O, A, c = orc.frame(cat["mask_red"], cat["constraints"], dtype=np.float32, mode=1, trig=1)
+    ref = orc.flow_from_offset(O)
+    assert float(c[-1]) == tab["variants"]["f32_sum64_spec_fma"]["final_cost"]
+    tab["perturbed_starts_product_arithmetic"] = perturbed_starts(
+        cat, ref, nseeds=n_product, trig=1, have=tab.get("perturbed_starts_product_arithmetic"))
+    json.dump(tab, open(path, "w"), indent=1)
+    orc.use_variant("nofma")
+    O, A, c = orc.frame(cat["mask_red"], cat["constraints"], dtype=np.float32, mode=1, trig=0)
+    ref2 = orc.flow_from_offset(O)
+    assert float(c[-1]) == tab["variants"]["f32_sum64_libm_nofma"]["final_cost"]
+    tab["perturbed_starts_f32_sum64_libm_nofma"] = perturbed_starts(
+        cat, ref2, nseeds=n_nofma, trig=0, have=tab.get("perturbed_starts_f32_sum64_libm_nofma"))
+    orc.use_variant(None)
+    json.dump(tab, open(path, "w"), indent=1)
+
+
 def main():
+    if "--perturbed-only" in sys.argv:
+        return more_perturbed()
     cat = helpers.load_cat512(HERE)
     gold = cat["golden_flow"]
     act = cat["mask_red"] == 0

@@ -97,14 +97,15 @@ def _deal(tiles):
 
 def _check_deal(tiles, n, tab):
     """every solve appears in exactly one launch with one contiguous rank range 0..wgs-1, enough workgroups for its
-    tiles (<= 9 each), granule blocks that do not overlap; a group of <= 64 workgroups sits on one XCD slot
-    (blockIdx & 7), a wider one on 2/4/8 whole aligned slots with ranks 64 q + j on its q-th slot"""
+    tiles (<= 9 each), granule blocks that do not overlap (a group of several runs owns whole blocks of 64 units);
+    a group of <= 64 workgroups sits on one XCD slot (blockIdx & 7); one of 65..128 has ranks 0..63 on a slot of its own
+    (its home, rank = local index) and the rest on ONE other slot; a wider one 4 or 8 whole aligned slots with ranks
+    64 q + j on its q-th slot"""
     seen = {}
     for s in range(n):
         slot, rank, wgs, gran = tab[s, :, 0], tab[s, :, 1], tab[s, :, 2], tab[s, :, 3]
         used = slot >= 0
-        assert int(wgs[used].sum() // 1) >= 0
-        gran_used = np.zeros(2 * 512 * 2 + 1, bool)
+        gran_used = np.zeros(2 * 2 * 1024 + 1, bool)
         for b in np.unique(slot[used]):
             assert b not in seen, "solve dealt twice"
             seen[int(b)] = s
@@ -113,14 +114,24 @@ def _check_deal(tiles, n, tab):
             assert (wgs[idx] == w).all() and len(idx) == w and sorted(rank[idx].tolist()) == list(range(w))
             assert w * 9 >= max(int(tiles[b]), 1)
             g = int(gran[idx[0]])
-            assert (gran[idx] == g).all() and g % 4 == 0 and not gran_used[g:g + 4 * w].any()
-            gran_used[g:g + 4 * w] = True
+            units = w if w <= 64 else -(-w // 64) * 64
+            assert (gran[idx] == g).all() and g % 4 == 0 and g + 4 * units <= 4 * 1024 and not gran_used[g:g + 4 * units].any()
+            gran_used[g:g + 4 * units] = True
             xs = idx & 7
             if w <= 64:
                 assert len(set(xs.tolist())) == 1
+            elif w <= 128:
+                hm = rank[idx] < 64
+                hx = set(xs[hm].tolist())
+                assert len(hx) == 1 and ((idx[hm] >> 3) == rank[idx][hm]).all()           # the home: a whole slot
+                assert (slot[(np.arange(512) & 7) == hx.pop()] == b).all()                 # ... that nobody shares
+                px = set(xs[~hm].tolist())
+                assert len(px) == 1 and px != set(xs[hm].tolist())                         # the piece: one other slot
+                loc = np.sort(idx[~hm] >> 3)
+                assert (np.diff(loc) == 1).all()                                           # consecutive local indices
             else:
                 k = w // 64
-                assert w % 64 == 0 and k in (2, 4, 8)
+                assert w % 64 == 0 and k in (4, 8)
                 a = int(xs.min())
                 assert a % k == 0 and set(xs.tolist()) == set(range(a, a + k))
                 assert ((rank[idx] >> 6) == (xs - a)).all() and ((rank[idx] & 63) == (idx >> 3)).all()
@@ -141,9 +152,23 @@ def test_resident_deal_packs_narrow_and_wide_solves():
     n, tab = _deal([1680, 1680, 1680])
     assert n == 2
     _check_deal([1680, 1680, 1680], n, tab)
-    n, tab = _deal([1680, 840, 500, 500, 500, 500, 500])                   # width 4 + width 2 + narrow ones
+    n, tab = _deal([1680, 840, 500, 500, 500, 500, 500])                   # width 4 + home-and-piece + narrow ones
     assert n == 2
     _check_deal([1680, 840, 500, 500, 500, 500, 500], n, tab)
+    # 1920x1080 --multseg segments (~716 tiles = 80 workgroups): a home XCD each plus a piece in a shared bin -- six
+    # to a launch (whole pairs of bins held four)
+    n, tab = _deal([716] * 6)
+    assert n == 1
+    _check_deal([716] * 6, n, tab)
+    assert (np.unique(tab[0, :, 2][tab[0, :, 0] >= 0]) >= 80).all() and (tab[0, :, 0] >= 0).sum() >= 6 * 80
+    n, tab = _deal([716] * 4)                                              # four of them: 128 workgroups each again
+    assert n == 1 and (tab[0, :, 2][tab[0, :, 0] >= 0] == 128).all()
+    _check_deal([716] * 4, n, tab)
+    n, tab = _deal([716] * 7)
+    assert n == 2
+    _check_deal([716] * 7, n, tab)
+    n, tab = _deal([716, 700, 650, 600, 590, 580, 300, 150, 20])           # mediums, their pieces and narrow solves mixed
+    _check_deal([716, 700, 650, 600, 590, 580, 300, 150, 20], n, tab)
     n, tab = _deal([4608])                                                 # the largest solve: all 512 workgroups
     assert n == 1 and (tab[0, :, 2] == 512).all()
     _check_deal([4608], n, tab)
