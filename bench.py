@@ -18,10 +18,13 @@ One JSON line on rank 0: metric/value/... plus
   roofline     : dominant PCG kernel.  achieved / peak / frac = SURVEY 8(d)'s figure: algorithmic bytes per launch /
                  average launch duration measured with HIP events around every launch (a separate, un-graphed pass)
                  against the 8 TB/s HBM peak.  The resident kernel keeps the PCG state on chip, so that figure exceeds 1
-                 and does NOT bind; `bound` names the ceiling that does, and the line carries the real utilisations:
+                 and does NOT bind; `bound` names the largest MEASURED fraction, and the line carries them all:
                  hbm_frac_by_counters (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE per launch / launch time / peak),
-                 valu_issue_frac (SQ_ACTIVE_INST_VALU quad-cycles x 4 / (1024 SIMDs x launch cycles)), wait_frac (share
-                 of an iteration inside the two group waits, instrumented build).  Those three come from
+                 valu_issue_frac (SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x launch cycles by GRBM_GUI_ACTIVE)) and
+                 valu_frac_of_ceiling (against the ceiling the phase-A instruction mix reaches in
+                 tools/microbench/issue_peak.hip), lds_frac (SQ_LDS_IDX_ACTIVE per CU-cycle against a saturated
+                 ds_read_b64 stream), wait_frac (share of an iteration inside the two group waits, instrumented
+                 build).  They come from
                  profiles/*_counters.json (tools/collect_profile.py) and are quoted only when that record was made for
                  this workload AND for the kernel sources as they are now (else null + the reason).
   cpu_baseline : the CPU oracle (kind "port") timed on this host on a bounded sample
@@ -353,7 +356,7 @@ def main():
                 ach = bytes_total / (tot_ms * 1e-3) / 1e9
                 frames_per_launch = S * float(G) / n
                 rl = {
-                    "bound": "valu_issue+group_wait", "kernel": "k_pcg_resident", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "bound": "group_wait", "kernel": "k_pcg_resident", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "equivalent_GBs": ach,
                     "avg_launch_us": tot_ms / n * 1e3, "launches": n,
                     "pcg_iterations_per_launch": tl, "frames_per_launch": frames_per_launch,
@@ -381,10 +384,12 @@ def main():
                       "note": "algorithmic bytes = %d (A) / %d (B) per active vertex per launch" % (BYTES_A, BYTES_B)}
             # counters of the same workload from rocprofv3 passes (collected separately: tools/collect_profile.py)
             rl["hbm_frac_by_counters"] = rl["valu_issue_frac"] = rl["wait_frac"] = None
+            rl["valu_frac_of_ceiling"] = rl["lds_frac"] = None
             if prof is None:
                 rl["counters_source"] = None
-                rl["counters_note"] = ("no profiles/*_counters.json matches this workload and the current kernel sources "
-                                       "(hash %s): traffic and utilisation figures withheld" % profile_key.source_hash())
+                rl["counters_note"] = ("no profiles/*_counters.json matches this workload and the current sources of %s "
+                                       "(hash %s): traffic and utilisation figures withheld"
+                                       % (kname, profile_key.source_hash(kname if kname == "k_pcg_resident" else kname[:7])))
             else:
                 pf, rec = prof
                 rl["counters_source"] = pf
@@ -397,14 +402,51 @@ def main():
                     rl["traffic_unit"] = "bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes)"
                     rl["traffic_detail"] = hb
                     rl["hbm_frac_by_counters"] = hb["total"] / launch_s / 1e9 / HBM_PEAK_GBS
+                # shader cycles of a launch: GRBM_GUI_ACTIVE is summed over the 8 XCDs (the clock the chip really held
+                # under this kernel); nominal 2.4 GHz where that pass is missing
+                cyc = pm["GRBM_GUI_ACTIVE"]["avg_per_launch"] / 8.0 if "GRBM_GUI_ACTIVE" in pm else launch_s * 2.4e9
+                rl["launch_cycles"] = cyc
+                rl["clock_GHz"] = cyc / (pmc_ns * 1e-9) / 1e9 if pmc_ns else None
+                ceil = profile_key.ceilings()
+                cd = ceil[1] if ceil else {}
+                rl["ceilings_source"] = ceil[0] if ceil else None
                 if "SQ_ACTIVE_INST_VALU" in pm:
-                    # SQ counters tick in quad-cycles; 256 CUs x 4 SIMDs; nominal 2.4 GHz
-                    rl["valu_issue_frac"] = pm["SQ_ACTIVE_INST_VALU"]["avg_per_launch"] * 4.0 / (1024.0 * launch_s * 2.4e9)
+                    # SQ_ACTIVE_INST_VALU counts one quad-cycle per vector instruction (= SQ_INSTS_VALU): x 4 cycles over the
+                    # cycles of the 1024 SIMDs.  Its CEILING depends on the instruction mix (tools/microbench/issue_peak.hip, two
+                    # wavefronts per SIMD: plain v_fma_f32 1.55, v_pk_fma_f32 0.90, the phase-A mix 0.98): the kernel is
+                    # quoted against the phase-A mix
+                    rl["valu_issue_frac"] = pm["SQ_ACTIVE_INST_VALU"]["avg_per_launch"] * 4.0 / (1024.0 * cyc)
+                    vc = cd.get("derived", {}).get("mix", {}).get("2_per_cu", {}).get("valu_active_x4_per_simd_cycle")
+                    if vc:
+                        rl["valu_ceiling"] = vc
+                        rl["valu_frac_of_ceiling"] = rl["valu_issue_frac"] / vc
+                if "SQ_LDS_IDX_ACTIVE" in pm:
+                    # cycles the LDS arrays of the 256 CUs were busy; ceiling = a saturated ds_read_b64 stream (0.89)
+                    lc = cd.get("lds_idx_active_ceiling")
+                    rl["lds_idx_active_frac"] = pm["SQ_LDS_IDX_ACTIVE"]["avg_per_launch"] / (256.0 * cyc)
+                    if lc:
+                        rl["lds_ceiling"] = lc
+                        rl["lds_frac"] = rl["lds_idx_active_frac"] / lc
+                    if "SQ_LDS_BANK_CONFLICT" in pm and pm["SQ_LDS_IDX_ACTIVE"]["avg_per_launch"] > 0:
+                        rl["lds_bank_conflict_share"] = pm["SQ_LDS_BANK_CONFLICT"]["avg_per_launch"] / pm["SQ_LDS_IDX_ACTIVE"]["avg_per_launch"]
                 if rec.get("stamps"):
                     rl["wait_frac"] = rec["stamps"].get("wait_frac")
                     rl["stamps_us_per_iteration"] = rec["stamps"].get("us")
                 if pmc_ns:
                     rl["rocprof_avg_launch_us"] = pmc_ns * 1e-3
+                # what binds = the largest measured fraction; inside the phases (the share of the time that is not group
+                # waits) the pipes are that much busier
+                if kname == "k_pcg_resident":
+                    fr = {"hbm": rl["hbm_frac_by_counters"], "valu_issue": rl["valu_frac_of_ceiling"], "lds": rl["lds_frac"],
+                          "group_wait": rl["wait_frac"]}
+                    fr = {k: v for k, v in fr.items() if v is not None}
+                    if fr:
+                        rl["bound"] = max(fr, key=fr.get)
+                        rl["measured_fractions"] = fr
+                    if rl["wait_frac"] is not None and rl["wait_frac"] < 1.0:
+                        for k in ("valu_frac_of_ceiling", "lds_frac"):
+                            if rl.get(k) is not None:
+                                rl[k + "_inside_phases"] = rl[k] / (1.0 - rl["wait_frac"])
             out["roofline"] = rl
             out["resident_path"] = stats.get("resident_launches", 0) > 0
             # measured device copy bandwidth next to the nominal peak: 1 GiB float32 copy, read + write

@@ -81,7 +81,7 @@ def pmc_pass(counters, bench_args, tag, outdir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("name", choices=sorted(CONFIGS))
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--skip", nargs="*", default=[], choices=["bench", "stats", "pmc", "stamps"])
     ap.add_argument("--bench-only", action="store_true",
                     help="re-run only the bench line (the counters record under profiles/ is kept and read back by it)")
@@ -146,6 +146,8 @@ def main():
         for tag, ctrs in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
                           ("sq1", ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU"]),
                           ("sq2", ["SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]),
+                          ("sq_lds", ["SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]),
+                          ("sq_lds2", ["SQ_WAIT_INST_LDS", "SQ_LDS_ADDR_CONFLICT", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"]),
                           ("grbm", ["GRBM_GUI_ACTIVE"])):
             for k, cs in pmc_pass(ctrs, short, tag, outdir).items():
                 pm.setdefault(k, {}).update(cs)
@@ -168,6 +170,10 @@ def main():
             for ln in open(log).read().splitlines():
                 if ln.startswith("{\"stamps\""):
                     rec["stamps"] = json.loads(ln)["stamps"]
+    # the record is tied to the sources of the kernel it is about (tools/profile_key.py)
+    ks = rec.get("kernel_stats", {})
+    rec["dominant_kernel"] = max(ks, key=lambda k: ks[k]["pct"]) if ks else None
+    rec["source_hash"] = profile_key.source_hash(rec["dominant_kernel"])
     open(pre + "_counters.json", "w").write(json.dumps(rec, indent=1) + "\n")
     print("wrote", pre + "_counters.json")
     # ---- 5. the bench line once more, now that its counters exist: the committed line carries traffic / utilisations ----
