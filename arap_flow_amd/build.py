@@ -40,6 +40,25 @@ def build(force=False, verbose=False):
     return OUT
 
 
+# libarapmatch.so: the matching stage in front of the solve (include/arap_match.h), its own library and sources
+MATCH_SRC = os.path.join(HERE, "csrc_dm", "arapmatch.hip")
+MATCH_OUT = os.path.join(OUT_DIR, "libarapmatch.so")
+
+
+def build_match(force=False, verbose=False):
+    deps = [MATCH_SRC, os.path.join(HERE, "..", "include", "arap_match.h")]
+    if not force and os.path.exists(MATCH_OUT) and all(os.path.getmtime(d) <= os.path.getmtime(MATCH_OUT) for d in deps):
+        return MATCH_OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
+           "-Wno-unused-function", "-o", MATCH_OUT, MATCH_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return MATCH_OUT
+
+
 HOST_DIR = os.path.join(HERE, "host")
 BIN_DIR = os.path.join(HERE, "bin")
 HOST_PROGRAMS = {"arap_deform": ["arap_deform.cpp", "png_io.cpp"], "warp_image": ["warp_image.cpp", "png_io.cpp"],
@@ -71,4 +90,5 @@ def build_host(force=False, verbose=False):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_match(force="--force" in sys.argv, verbose=True)
     build_host(force="--force" in sys.argv, verbose=True)

@@ -20,9 +20,10 @@ pairs serially and forks one ARAP child per hand-out, which would leave the GPU 
     put to work): lines go to whichever GPU has room, as the reference's GPU queue does (para_gen.py:441-445,560-567).
     A foreign --arap_bin (argv contract of arap_deform only) is run once per hand-out of up to --narap lines instead.
   * A worker that exits non-zero fails the run at once (the reference hangs: its GPU id never returns to the queue).
-  * DeepMatching (para_gen.py:227-240) is an external binary that is not part of the reference tree.  Either
-    pass --dm_bin (called exactly as the reference does) or --matches DIR holding precomputed
-    `x1 y1 x2 y2 ...` lines at DIR/<seq>/<frame>.txt.
+  * DeepMatching (para_gen.py:227-240) is an external binary that is not part of the reference tree.  Pass --dm_bin
+    PATH (called exactly as the reference does), --dm_bin builtin (this repo's GPU implementation of the published
+    algorithm, libarapmatch.so: every pair is matched first, then the ARAP workers start -- the two must not share a
+    GPU at the same time) or --matches DIR holding precomputed `x1 y1 x2 y2 ...` lines at DIR/<seq>/<frame>.txt.
   * --bg_dir replaces the hard-coded 'data/naturedata' (para_gen.py:16); without it frames keep a black
     background.
 """
@@ -61,6 +62,13 @@ def run_matching(flags, p, seq, stem):
         src = osp.join(flags.matches, seq, stem + ".txt")
         assert osp.exists(src), "File not found: \n%s" % src
         open(p["cstr_tmp"], "w").write(open(src).read())
+        return
+    if flags.dm_bin == "builtin":
+        # this repo's matcher (libarapmatch.so, include/arap_match.h) through the matcher server of one of the GPUs: same
+        # inputs, same -ngh_rad, same output file format as the binary below
+        from arap_flow_amd import match_server
+        socks = flags.dm_sockets
+        match_server.request(socks[hash((seq, stem)) % len(socks)], p["rgb1_org"], p["rgb2_org"], p["cstr_tmp"], 100)
         return
     cmd = "./%s %s %s -nt 0 -out %s -ngh_rad 100 " % (flags.dm_bin, p["rgb1_org"], p["rgb2_org"], p["cstr_tmp"])
     status = subprocess.call(cmd, shell=True)
@@ -336,6 +344,35 @@ def scan(flags, input_root, output_root):
     return all_paths
 
 
+def start_matchers(flags, output_root):
+    """one matcher server per --gpu id (arap_flow_amd/match_server.py); their socket paths go to the pool jobs in flags"""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="arapmatch_")
+    procs, socks = [], []
+    for g in flags.gpu:
+        sock = osp.join(d, "gpu%d.sock" % g)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(g))
+        pr = subprocess.Popen([sys.executable, "-m", "arap_flow_amd.match_server", sock], cwd=HERE, env=env,
+                              stdout=subprocess.PIPE, text=True)
+        line = pr.stdout.readline()
+        assert line.strip() == "Ready", "matcher server on GPU %d did not start" % g
+        procs.append(pr)
+        socks.append(sock)
+    flags.dm_sockets = socks
+    return procs
+
+
+def stop_matchers(flags, procs):
+    from arap_flow_amd import match_server
+    for sock in getattr(flags, "dm_sockets", []):
+        match_server.stop(sock)
+    for pr in procs:
+        try:
+            pr.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+
+
 def main(flags):
     t_start = time.time()
     input_root, output_root = flags.input.rstrip(osp.sep), flags.output.rstrip(osp.sep)
@@ -380,11 +417,23 @@ def main(flags):
             counts["frames_done"] += 1
             posts.append(pool.apply_async(finish_frame, ((rec["arap_path"], rec["seg_paths"], rec["bg"]),)))
 
+    # --dm_bin builtin: the matcher and the solver must not share a GPU at the same time (the solver's resident kernel
+    # needs the whole chip: arap_resident.h), so the run has two phases -- every pair is prepared and matched first
+    # (one matcher server per GPU id), the servers exit, then the ARAP workers start and are fed.
+    prepared = None
+    if flags.dm_bin == "builtin":
+        servers = start_matchers(flags, output_root)
+        try:
+            jobs = ((flags, p, bg) for p, bg in zip(all_paths, picks))
+            prepared = list(pool.imap(prepare_pair, jobs, chunksize=1))
+        finally:
+            stop_matchers(flags, servers)
+        print("Matching		%d pairs [Done]" % len(prepared))
     workers = GpuWorkers(flags.arap_bin, flags.gpu, flags.narap, serve, on_done)
     n_solves = n_frames = 0
     try:
         jobs = ((flags, p, bg) for p, bg in zip(all_paths, picks))
-        for i, res in enumerate(pool.imap(prepare_pair, jobs, chunksize=1)):
+        for i, res in enumerate(prepared if prepared is not None else pool.imap(prepare_pair, jobs, chunksize=1)):
             print("%.3f%%" % (float(i) * 100 / len(all_paths)))
             workers.check()
             if res is None:
@@ -459,7 +508,8 @@ def parse(argv=None):
         pass
     parser.add_argument("--jobs", type=int, default=max(1, min(96, ncpu - 2)),
                         help="worker processes for the per-pair front end and back end")
-    parser.add_argument("--dm_bin", default=None, help="Path to the deep matching binary")
+    parser.add_argument("--dm_bin", default=None,
+                        help="Path to the deep matching binary, or 'builtin': this repo's GPU matcher (libarapmatch.so)")
     parser.add_argument("--matches", default=None, help="directory of precomputed matches (instead of --dm_bin)")
     parser.add_argument("--bg_dir", default=None, help="directory of background images")
     flags = parser.parse_args(argv)
@@ -467,7 +517,7 @@ def parse(argv=None):
         flags.size = tuple(int(s) for s in flags.size)
     assert 0 < flags.fd < 20, "Invalid fd number!"
     assert flags.dm_bin is not None or flags.matches is not None, "give --dm_bin or --matches"
-    if flags.dm_bin is not None:
+    if flags.dm_bin is not None and flags.dm_bin != "builtin":
         assert osp.exists(flags.dm_bin), "File not found " + flags.dm_bin
     return flags
 

@@ -91,6 +91,38 @@ def test_para_gen_end_to_end(tmp_path, multseg):
     assert not [f for f in os.listdir(outp / "Flow" / "a") if "_seg" in f]          # flattened and removed
 
 
+
+def test_para_gen_with_the_builtin_matcher(tmp_path):
+    """`para_gen.py --dm_bin builtin`: the pairs are matched by this repo's GPU matcher (libarapmatch.so through the
+    matcher server; the reference calls the external DeepMatching binary here, para_gen.py:227-240), the matches are
+    filtered into constraints and solved.  Frame 2 of every pair is frame 1 moved by a few pixels, label mask included:
+    the flow written for the object must be that translation."""
+    W, H, dx, dy = 192, 128, 5, -3
+    inp, outp = tmp_path / "in", tmp_path / "out"
+    os.makedirs(inp / "orgRGB" / "s"); os.makedirs(inp / "orgMasks" / "s")
+    rng = np.random.default_rng(7)
+    big = synth.make_rgb(W + 64, H + 64, 5).astype(np.int32) + rng.integers(-40, 41, (H + 64, W + 64, 1))
+    big = np.clip(big, 0, 255).astype(np.uint8)
+    lab_big = np.zeros((H + 64, W + 64), np.uint8)
+    yy, xx = np.mgrid[0:H + 64, 0:W + 64]
+    lab_big[((xx - 32 - W / 2) / (W * 0.28)) ** 2 + ((yy - 32 - H / 2) / (H * 0.30)) ** 2 < 1.0] = 1
+    for n in range(3):                                                  # frame n = the content moved by n * (dx, dy)
+        y0, x0 = 32 - n * dy, 32 - n * dx
+        Image.fromarray(big[y0:y0 + H, x0:x0 + W]).save(inp / "orgRGB" / "s" / ("%05d.png" % n))
+        Image.fromarray(lab_big[y0:y0 + H, x0:x0 + W]).save(inp / "orgMasks" / "s" / ("%05d.png" % n))
+    _run([osp.join(ROOT, "para_gen.py"), "--input", str(inp), "--output", str(outp), "--gpu", "0", "--fd", "1",
+          "--dm_bin", "builtin"], str(tmp_path))
+    lst = open(outp / "all_files.list").read().splitlines()
+    assert len(lst) == 2
+    cst = open(outp / "tmpCnstr" / "s" / "00000.txt").read().split()
+    assert int(cst[0]) > 50                                            # matches on the object that passed the filter
+    f = flo.flow_read(lst[0].split(" ")[2])
+    lab = np.array(Image.open(inp / "orgMasks" / "s" / "00000.png")) != 0
+    core = lab & np.roll(lab, 8, 0) & np.roll(lab, -8, 0) & np.roll(lab, 8, 1) & np.roll(lab, -8, 1)
+    med = np.median(f[core], axis=0)
+    assert abs(med[0] - dx) <= 1.0 and abs(med[1] - dy) <= 1.0, med
+
+
 def _bins():
     from arap_flow_amd import build
     return {osp.basename(o): o for o in build.build_host()}
