@@ -58,6 +58,7 @@ SYMBOLS = [
     ("ArapFlow_ResidentDeal", _I, [C.POINTER(C.c_int), C.c_uint, C.POINTER(C.c_int), C.c_uint]),
     ("ArapFlow_ResidentTiles", _I, [_VP, _U, _U, _I, C.POINTER(C.c_int), _U, C.POINTER(C.c_int)]),
     ("ArapFlow_SolverResidentLayout", _I, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("ArapFlow_SolverLeanStream", _I, [_VP]),
     ("ArapFlow_ResidentFailed", _I, [_VP]),
     ("ArapFlow_SolverStamps", _I, [_VP, _VP]),
     ("ArapFlow_WarpScratchBytes", C.c_uint64, [_U, _U]),

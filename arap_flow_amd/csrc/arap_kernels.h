@@ -370,19 +370,36 @@ __global__ __launch_bounds__(256) void k_pcg_b4(PlanDev pd, int l)
 
 // ------------------------------------------------------------------------------------------------
 // PCGLinearUpdate: X += delta on non-excluded vertices
-__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd)
+// lag_l >= 0 (the lean streaming schedule, arap_stream.h): the delta images still lack the last PCG iteration's
+// update delta += alpha_l p_l (every other iteration's was made by phase A of the iteration after it): made here.
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd, int lag_l)
 {
     const VIdx v = vidx(pd);
     if (pd.res_err && *pd.res_err) return;          // the resident kernel gave up: leave X as it was (see PlanDev)
     if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
+    float alpha = 0.f;
+    if (lag_l >= 0) {
+        const double* rs = pd.red + (size_t)v.b * pd.nslots * NSHARD;
+        const float rho = read_scalar(rs + (size_t)(2 * lag_l) * NSHARD);
+        const float sigma = read_scalar(rs + (size_t)(2 * lag_l + 1) * NSHARD);
+        if (sigma > 0.f) alpha = rho / sigma;
+    }
     if (!v.in || !(pd.flags[v.g] & F_ACT)) return;
     const Slot sl = pd.slots[v.b];
-    const float2 d = pd.deltaO[v.g];
+    float2 d = pd.deltaO[v.g];
+    float da = pd.deltaA[v.g];
+    if (lag_l >= 0) {
+        const float2 p = ((lag_l & 1) ? pd.pO0 : pd.pO1)[v.g];          // written by phase A of iteration lag_l
+        const float pa = ((lag_l & 1) ? pd.pA0 : pd.pA1)[v.g];
+        d.x = fmaf(alpha, p.x, d.x);
+        d.y = fmaf(alpha, p.y, d.y);
+        da = fmaf(alpha, pa, da);
+    }
     float2 o = sl.O[v.i];
     o.x = o.x + d.x;
     o.y = o.y + d.y;
     sl.O[v.i] = o;
-    sl.A[v.i] = sl.A[v.i] + pd.deltaA[v.g];
+    sl.A[v.i] = sl.A[v.i] + da;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -311,6 +311,255 @@ __global__ __launch_bounds__(256) void k_pcg_a_march(PlanDev pd, int l, int stri
     red_finish<1>(pd, b, rt, sigma_l, nullptr);
 }
 
+// ---- the lean schedule (frame-solver plans): 126 instead of 146 bytes per vertex and iteration ------------------------
+// What the two phases of an iteration must do is fixed by the two sums (sigma = p.Ap needs every p, rho' = z.r needs the
+// new r everywhere); WHERE the element-wise work is done is free.  k_pcg_a_march2 / k_pcg_b4_r move it so that fewer
+// bytes travel (same operations on the same operands: the bits do not change):
+//   * z = M^-1 r is never stored: phase B needs it only for its dot product, and phase A forms it again from r, M^-1_A
+//     and the flag byte (M^-1_O is a function of the flags) for every vertex it stages      (-12 B written, +4 B read)
+//   * delta += alpha p of iteration l-1 is done by phase A of iteration l, which has p_{l-1} in hand anyway; phase B no
+//     longer reads p or touches delta (the last iteration's update is folded into k_gn_update)     (-12 B read)
+// Phase A': reads p3 r3 M^-1_A cs2 flags delta3, writes p3 Ap3 delta3 (85 B); phase B': reads r3 Ap3 M^-1_A flags, writes
+// r3 (41 B).
+#ifndef ARAP_MARCH2_WAVES
+#define ARAP_MARCH2_WAVES 1
+#endif
+template <int RB>
+__global__ __launch_bounds__(256, ARAP_MARCH2_WAVES) void k_pcg_a_march2(PlanDev pd, int l, int stripsX, int chunksY, int chunk8)
+{
+    constexpr int LW = TILE_X + 2, RROWS = 16;                    // ring: 4 blocks x 4 rows
+    __shared__ float2 sP[RROWS][LW];
+    __shared__ float2 sC[RROWS][LW];
+    __shared__ float sA[RROWS][LW];
+    __shared__ unsigned char sF[RROWS][TILE_X];
+    __shared__ float moLUT[12];
+    int sx, cy, b;
+    unsigned lb;
+    const bool has_strip = xcd_tile(stripsX, chunksY, chunk8, sx, cy, b, lb);
+    const unsigned nlb = 8u * (unsigned)chunk8;
+    double* const sigma_l = pd.red + ((size_t)b * pd.nslots + (2 * l + 1)) * NSHARD;
+    const unsigned rtag = red_tag(pd, b, lb);
+    if (!has_strip) { block_reduce_fixed<1>(pd, b, lb, nlb, 0.0, 0.0, sigma_l, nullptr, rtag); return; }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int W = pd.W, H = pd.H;
+    const size_t gb = (size_t)b * pd.N;
+    const int x = sx * TILE_X + lane;
+    const int ybase = cy * (4 * RB);
+    const int nblk = min(RB, (H - ybase + 3) >> 2);
+    const uint8_t* tact = pd.tileact + (size_t)b * pd.tilesX * pd.tilesY + sx;
+    const int tyb = ybase >> 2;
+    auto active = [&](int blk) {
+        const int ty = tyb + blk;
+        return ty >= 0 && ty < pd.tilesY && tact[(size_t)ty * pd.tilesX] != 0;
+    };
+    {
+        bool any = false;
+        for (int k = 0; k < nblk; ++k) any = any || active(k);
+        if (!any) { block_reduce_fixed<1>(pd, b, lb, nlb, 0.0, 0.0, sigma_l, nullptr, rtag); return; }
+    }
+    const Slot sl = pd.slots[b];
+    if (threadIdx.x < 10) {                                       // M^-1_O by (degree, fit), as k_gn_init computes it
+        const int deg = threadIdx.x % 5, fit = threadIdx.x / 5;
+        float dO = 0.f;
+        for (int k = 0; k < deg; ++k) dO = dO + (sl.wr * sl.wr + sl.wr * sl.wr);
+        if (fit) dO = fmaf(sl.wf, sl.wf, dO);
+        moLUT[threadIdx.x] = ginv(dO);
+    }
+    const float2* __restrict__ pinO = (l & 1) ? pd.pO1 : pd.pO0;
+    const float* __restrict__ pinA = (l & 1) ? pd.pA1 : pd.pA0;
+    float2* __restrict__ poutO = (l & 1) ? pd.pO0 : pd.pO1;
+    float* __restrict__ poutA = (l & 1) ? pd.pA0 : pd.pA1;
+    float beta = 0.f, alpha_prev = 0.f;
+    if (l > 0) {
+        const double* rs = pd.red + (size_t)b * pd.nslots * NSHARD;
+        const float rhoNew = read_scalar(rs + (size_t)(2 * l) * NSHARD);
+        const float rhoOld = read_scalar(rs + (size_t)(2 * l - 2) * NSHARD);
+        const float sigOld = read_scalar(rs + (size_t)(2 * l - 1) * NSHARD);
+        if (rhoOld > 0.f) beta = rhoNew / rhoOld;
+        if (sigOld > 0.f) alpha_prev = rhoOld / sigOld;           // alpha of iteration l - 1 (PCGStep2 :446-489)
+    }
+    __syncthreads();
+    struct Stage {
+        float2 pO, rO, cs, hpO, hrO, hcs, dO;
+        float pA, rA, mA, hpA, hrA, hmA, dA;
+        unsigned f, hf;
+        int i, hcol, hi;
+        bool owned;
+    };
+    auto issue = [&](int blk) {
+        Stage s;
+        s.i = -1; s.hcol = -1; s.hi = -1; s.f = 0u; s.hf = 0u; s.owned = blk >= 0 && blk < nblk;
+        s.pO = s.rO = s.cs = s.hpO = s.hrO = s.hcs = s.dO = make_float2(0.f, 0.f);
+        s.pA = s.rA = s.mA = s.hpA = s.hrA = s.hmA = s.dA = 0.f;
+        const int y = ybase + 4 * blk + w;
+        const bool row_wanted = blk <= nblk && (blk >= 0 || w == 3) && (blk < nblk || w == 0);
+        if (!row_wanted || y < 0 || y >= H || !active(blk)) return s;
+        if (x < W) {
+            s.i = x + W * y;
+            s.f = pd.flags[gb + s.i];
+            s.pO = pinO[gb + s.i]; s.pA = pinA[gb + s.i]; s.cs = pd.cs[gb + s.i];
+            if (l > 0) {
+                s.rO = pd.rO[gb + s.i]; s.rA = pd.rA[gb + s.i]; s.mA = pd.preA[gb + s.i];
+                if (s.owned) { s.dO = pd.deltaO[gb + s.i]; s.dA = pd.deltaA[gb + s.i]; }
+            }
+            if (lane == 0 && x > 0) { s.hi = s.i - 1; s.hcol = 0; }
+            if ((lane == TILE_X - 1 || x == W - 1) && x + 1 < W) { s.hi = s.i + 1; s.hcol = lane + 2; }
+            if (s.hi >= 0) {
+                s.hpO = pinO[gb + s.hi]; s.hpA = pinA[gb + s.hi]; s.hcs = pd.cs[gb + s.hi];
+                if (l > 0) { s.hf = pd.flags[gb + s.hi]; s.hrO = pd.rO[gb + s.hi]; s.hrA = pd.rA[gb + s.hi]; s.hmA = pd.preA[gb + s.hi]; }
+            }
+        }
+        return s;
+    };
+    auto finish = [&](int blk, const Stage& s) {
+        if (s.i < 0) return;
+        const int r = ((blk & 3) << 2) | w;
+        float2 pO = s.pO;
+        float pA = s.pA;
+        if (l > 0) {
+            if (s.owned && (s.f & F_ACT)) {                          // delta += alpha_{l-1} p_{l-1}
+                pd.deltaO[gb + s.i] = make_float2(fmaf(alpha_prev, pO.x, s.dO.x), fmaf(alpha_prev, pO.y, s.dO.y));
+                pd.deltaA[gb + s.i] = fmaf(alpha_prev, pA, s.dA);
+            }
+            const float mo = moLUT[__popc(s.f & 15u) + 5 * (int)((s.f >> 4) & 1u)];
+            const float zx = mo * s.rO.x, zy = mo * s.rO.y, za = s.mA * s.rA;      // z = M^-1 r, as phase B formed it
+            pO.x = fmaf(beta, pO.x, zx);
+            pO.y = fmaf(beta, pO.y, zy);
+            pA = fmaf(beta, pA, za);
+        }
+        sP[r][lane + 1] = pO; sA[r][lane + 1] = pA; sC[r][lane + 1] = s.cs;
+        sF[r][lane] = (unsigned char)s.f;
+        if (s.owned && (s.f & F_ACT)) { poutO[gb + s.i] = pO; poutA[gb + s.i] = pA; }
+        if (s.hcol >= 0) {
+            float2 hO = s.hpO;
+            float hA = s.hpA;
+            if (l > 0) {
+                const float mo = moLUT[__popc(s.hf & 15u) + 5 * (int)((s.hf >> 4) & 1u)];
+                hO.x = fmaf(beta, hO.x, mo * s.hrO.x);
+                hO.y = fmaf(beta, hO.y, mo * s.hrO.y);
+                hA = fmaf(beta, hA, s.hmA * s.hrA);
+            }
+            sP[r][s.hcol] = hO; sA[r][s.hcol] = hA; sC[r][s.hcol] = s.hcs;
+        }
+    };
+    {
+        const Stage a = issue(-1), c0 = issue(0), c1 = issue(1);
+        finish(-1, a); finish(0, c0); finish(1, c1);
+    }
+    __syncthreads();
+    const float wr2 = sl.wr * sl.wr, wf2 = sl.wf * sl.wf;
+    double d = 0.0;
+    float2 pendO = make_float2(0.f, 0.f);
+    float pendA = 0.f;
+    int pendI = -1;
+    for (int k = 0; k < nblk; ++k) {
+        const Stage nx = issue(k + 2);
+        if (pendI >= 0) { pd.ApO[gb + pendI] = pendO; pd.ApA[gb + pendI] = pendA; pendI = -1; }
+        const int y = ybase + 4 * k + w;
+        if (active(k) && x < W && y < H) {
+            const int r = ((k & 3) << 2) | w, ru = (r + RROWS - 1) & (RROWS - 1), rd = (r + 1) & (RROWS - 1);
+            const unsigned f = sF[r][lane];
+            if (f & F_ACT) {
+                const int c = lane + 1;
+                const float2 pO = sP[r][c];
+                const float pA = sA[r][c];
+                const float2 csi = sC[r][c];
+                const float ci = csi.x, si = csi.y;
+                float ax = 0.f, ay = 0.f, aa = 0.f;
+#define MARCH_EDGE(BIT, RR, CC, NQX, NQY, NHX, NHY, QX, QY)                                         \
+                if (f & (BIT)) {                                                                    \
+                    const float2 qO = sP[RR][CC];                                                   \
+                    const float qA = sA[RR][CC];                                                    \
+                    const float2 csn = sC[RR][CC];                                                  \
+                    const float cn = csn.x, sn = csn.y;                                             \
+                    const float px = pO.x - qO.x, py = pO.y - qO.y;                                 \
+                    const float tx_ = fmaf(NQX, pA, px), ty_ = fmaf(NQY, pA, py);                   \
+                    ax = fmaf(wr2, fmaf(NHX, qA, px + tx_), ax);                                    \
+                    ay = fmaf(wr2, fmaf(NHY, qA, py + ty_), ay);                                    \
+                    aa = fmaf(-wr2, fmaf(QX, tx_, (QY) * ty_), aa);                                 \
+                    (void)cn; (void)sn;                                                             \
+                }
+                MARCH_EDGE(F_E0, r, c + 1,    -si,  ci,   -sn,  cn,    si, -ci)      // s=( 1, 0)
+                MARCH_EDGE(F_E1, r, c - 1,     si, -ci,    sn, -cn,   -si,  ci)      // s=(-1, 0)
+                MARCH_EDGE(F_E2, rd, c,       -ci, -si,   -cn, -sn,    ci,  si)      // s=( 0, 1)
+                MARCH_EDGE(F_E3, ru, c,        ci,  si,    cn,  sn,   -ci, -si)      // s=( 0,-1)
+#undef MARCH_EDGE
+                if (f & F_FIT) {
+                    ax = fmaf(wf2, pO.x, ax);
+                    ay = fmaf(wf2, pO.y, ay);
+                }
+                pendI = x + W * y;
+                pendO = make_float2(ax, ay);
+                pendA = aa;
+                d += (double)dot3(pO.x, pO.y, pA, ax, ay, aa);
+            }
+        }
+        finish(k + 2, nx);
+        __syncthreads();
+    }
+    const RedTicket rt = red_arrive<1>(pd, b, lb, nlb, d, 0.0, rtag);
+    if (pendI >= 0) { pd.ApO[gb + pendI] = pendO; pd.ApA[gb + pendI] = pendA; }
+    red_finish<1>(pd, b, rt, sigma_l, nullptr);
+}
+
+// Phase B of the lean schedule: r -= alpha Ap; rho' = (M^-1 r) . r.  Four consecutive vertices per lane, 16-byte accesses.
+__global__ __launch_bounds__(256) void k_pcg_b4_r(PlanDev pd, int l)
+{
+    __shared__ float moLUT[12];
+    const int b = blockIdx.y;
+    const unsigned rtag = red_tag(pd, b, blockIdx.x);
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int nq = pd.N >> 2;
+    const size_t gb = (size_t)b * pd.N;
+    {
+        const Slot sl = pd.slots[b];
+        if (threadIdx.x < 10) {
+            const int deg = threadIdx.x % 5, fit = threadIdx.x / 5;
+            float dO = 0.f;
+            for (int k = 0; k < deg; ++k) dO = dO + (sl.wr * sl.wr + sl.wr * sl.wr);
+            if (fit) dO = fmaf(sl.wf, sl.wf, dO);
+            moLUT[threadIdx.x] = ginv(dO);
+        }
+    }
+    const double* rs = pd.red + (size_t)b * pd.nslots * NSHARD;
+    const float rho = read_scalar(rs + (size_t)(2 * l) * NSHARD);
+    const float sigma = read_scalar(rs + (size_t)(2 * l + 1) * NSHARD);
+    float alpha = 0.f;
+    if (sigma > 0.f) alpha = rho / sigma;
+    __syncthreads();
+    double d = 0.0;
+    const unsigned fw = q < nq ? ((const unsigned*)(pd.flags + gb))[q] : 0u;
+    const bool any_active = (fw & 0x20202020u) != 0u;
+    float4* rO4 = (float4*)(pd.rO + gb);
+    float4* rA4 = (float4*)(pd.rA + gb);
+    float apo[8], r[8], apa[4], ma[4], ra[4];
+    if (any_active) {
+        const float4* ApO4 = (const float4*)(pd.ApO + gb);
+        const float4* ApA4 = (const float4*)(pd.ApA + gb);
+        const float4* mA4 = (const float4*)(pd.preA + gb);
+        *(float4*)&apo[0] = ApO4[2 * q]; *(float4*)&apo[4] = ApO4[2 * q + 1];
+        *(float4*)&r[0] = rO4[2 * q]; *(float4*)&r[4] = rO4[2 * q + 1];
+        *(float4*)apa = ApA4[q]; *(float4*)ma = mA4[q]; *(float4*)ra = rA4[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned fk = (fw >> (8 * k)) & 0xffu;
+            if (!(fk & F_ACT)) continue;
+            const float mo = moLUT[__popc(fk & 15u) + 5 * (int)((fk >> 4) & 1u)];
+            r[2 * k] = fmaf(-alpha, apo[2 * k], r[2 * k]);
+            r[2 * k + 1] = fmaf(-alpha, apo[2 * k + 1], r[2 * k + 1]);
+            ra[k] = fmaf(-alpha, apa[k], ra[k]);
+            const float zx = mo * r[2 * k], zy = mo * r[2 * k + 1], za = ma[k] * ra[k];
+            d += (double)dot3(zx, zy, za, r[2 * k], r[2 * k + 1], ra[k]);
+        }
+    }
+    const RedTicket rt = red_arrive<1>(pd, b, blockIdx.x, gridDim.x, d, 0.0, rtag);
+    if (any_active) {
+        rO4[2 * q] = *(float4*)&r[0]; rO4[2 * q + 1] = *(float4*)&r[4];
+        rA4[q] = *(float4*)ra;
+    }
+    red_finish<1>(pd, b, rt, pd.red + ((size_t)b * pd.nslots + (2 * l + 2)) * NSHARD, nullptr);
+}
+
 // Phase B (k_pcg_b4's update, four consecutive vertices per lane, 16-byte accesses) without the z and preO reads.
 // grid = (ceil(N/4/256), frames), block = 256.  Gauss-Newton plans with N % 4 == 0 only.
 __global__ __launch_bounds__(256) void k_pcg_b4_lean(PlanDev pd, int l)

@@ -127,7 +127,8 @@ struct Opt_Plan {
     int g_l = -1, g_nb = -1, g_res = -1;   // g_res > 0: resident launches per step, < 0: two-kernel phase-A variant
     // resident PCG (arap_resident.h): only for the frame solver (pixel-grid UrShape, host-known masks)
     bool res_capable = false;       // device has 256 CUs and the kernel fits one workgroup per CU
-    bool res_frames = false;        // plan is driven by ArapFlow_Solver
+    bool res_frames = false;        // plan is driven by ArapFlow_Solver (and the resident resources exist)
+    bool res_frames_any = false;    // plan is driven by ArapFlow_Solver, whatever the device
     bool grid_u = false;            // UrShape is the pixel grid on every active vertex (frame solver: always; drop-in:
                                     // what the last analysis found): the streaming phase A without UrShape loads applies
     // ArapFlow_Solver reports one cost, the one after the last step of the last ramp iteration: the costs the
@@ -777,6 +778,18 @@ static bool plan_active_tiles_majority(const Opt_Plan* p)
     return 2 * act >= (long)p->nb * all;
 }
 
+// The lean streaming schedule (arap_stream.h: k_pcg_a_march2 / k_pcg_b4_r, 126 instead of 146 B per vertex and
+// iteration): frame-solver plans only (nothing else reads z or an up-to-date delta between the two phases), pixel-grid
+// UrShape, Gauss-Newton, 16-byte alignment of every frame's images -- and most tiles active: its phase A carries more
+// loads per stage, which pays where the rows are full (1920x1080 mask == 0: 94.2 -> 86.3 ms per 4 x 400 iterations; eight
+// 854x480 mask == 0 frames: 167.5 -> 138.9) and loses on sparse masks (eight DAVIS-shaped frames: 75.9 -> 80.0).
+// ARAPOPT_STREAM_A=2 keeps the round-2 pair.
+static bool plan_lean_stream(const Opt_Plan* p)
+{
+    return p->res_frames_any && p->grid_u && !p->pd.lm && p->st->tile < 0 && (p->N & 3) == 0 && !p->st->force_b8 &&
+           p->st->stream_a == 0 && plan_active_tiles_majority(p);
+}
+
 // phase A of the two-kernel path: direct-load kernel or an LDS-staged tile shape (ArapFlow_SetTile)
 static const int kTileShapes[6][2] = {{0, 0}, {16, 16}, {32, 8}, {64, 4}, {32, 16}, {64, 8}};
 
@@ -786,8 +799,17 @@ static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
     if (v < 0 && p->grid_u && !p->pd.lm) {
         // default for the pixel-grid UrShape (every frame-solver plan): the marching kernel of arap_stream.h -- no
         // UrShape loads, every vertex fetched once, XCD-aware strip order; 1-D launch of frames x 8 x ceil(tiles / 8)
-        constexpr int RB = 5;                                  // 20 rows per workgroup
-        const int sX = p->pd.tilesX, cY = (p->H + 4 * RB - 1) / (4 * RB), chunk = (sX * cY + 7) / 8;
+        // blocks of 4 rows a workgroup marches through: 5 for the round-2 pair, 7 for the lean schedule, whose phase A holds
+        // more loads per stage (84 VGPRs: 5 workgroups per CU) -- 30 x 39 = 1170 workgroups at 1920x1080 are all resident at
+        // once with 7 blocks, 1624 with 5 are not (sweep 3 / 5 / 6 / 7 / 8 / 10: 46.6 / 43.8 / 44.5 / 38.4 / 38.6 / 42.2 us)
+        constexpr int RB = 5, RB2 = 7;
+        const int sX = p->pd.tilesX;
+        if (p->st->stream_a == 0 && plan_lean_stream(p)) {
+            const int cY2 = (p->H + 4 * RB2 - 1) / (4 * RB2), chunk2 = (sX * cY2 + 7) / 8;
+            LAUNCH(p, s, "PCGStepA", (k_pcg_a_march2<RB2>), dim3((unsigned)(p->nb * 8 * chunk2)), dim3(256), p->pd, l, sX, cY2, chunk2);
+            return;
+        }
+        const int cY = (p->H + 4 * RB - 1) / (4 * RB), chunk = (sX * cY + 7) / 8;
         if (p->st->stream_a == 1) {
             constexpr int TX = 64, TY = 8;
             const int tX = (p->W + TX - 1) / TX, tY = (p->H + TY - 1) / TY, ch = (tX * tY + 7) / 8;
@@ -865,14 +887,17 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
             launch_pcg_a(p, s, l);
             if ((p->N & 3) == 0 && !p->pd.lm && !p->st->force_b8) {     // 16-byte accesses need every frame's images 16-byte aligned
                 const dim3 gq((p->N / 4 + 255) / 256, p->nb, 1);
-                if (p->st->tile < 0) LAUNCH(p, s, "PCGStepB", k_pcg_b4_lean, gq, dim3(256), p->pd, l);
+                if (plan_lean_stream(p)) LAUNCH(p, s, "PCGStepB", k_pcg_b4_r, gq, dim3(256), p->pd, l);
+                else if (p->st->tile < 0) LAUNCH(p, s, "PCGStepB", k_pcg_b4_lean, gq, dim3(256), p->pd, l);
                 else LAUNCH(p, s, "PCGStepB", k_pcg_b4, gq, dim3(256), p->pd, l);        // (explicit variants: the sweep's baseline)
             }
             else
                 LAUNCH(p, s, "PCGStepB", k_pcg_b, g, b, p->pd, l);
         }
     }
-    LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl);
+    // (the lean streaming schedule leaves the last iteration's delta += alpha p to the update kernel)
+    const int lag = (!res && L > 0 && plan_lean_stream(p)) ? L - 1 : -1;
+    LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl, lag);
 }
 
 static void plan_gn_step(Opt_Plan* p)
@@ -906,7 +931,8 @@ static void plan_gn_step(Opt_Plan* p)
         return;
     }
     // the captured launches bake in the path (resident: number of launches; two-kernel: phase-A variant)
-    const int res_now = res ? p->res_sets : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p)) - 16 * (int)p->grid_u;
+    const int res_now = res ? p->res_sets : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p)) - 16 * (int)p->grid_u -
+                                            32 * (int)plan_lean_stream(p);
     int maxn_now = 0;
     if (res && p->res_frames && p->d_t64list)
         for (int k = 0; k < p->nb; ++k) maxn_now = std::max(maxn_now, p->h_t64n[k]);
@@ -1089,7 +1115,7 @@ static int plan_step_lm(Opt_Plan* p)
     const Slot& sl = p->hslots[0];
     HC(hipMemcpyAsync(p->prevO, sl.O, N * sizeof(float2), hipMemcpyDeviceToDevice, s));   // savePreviousUnknowns
     HC(hipMemcpyAsync(p->prevA, sl.A, N * sizeof(float), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_gn_update, g, b, 0, s, p->pd);
+    hipLaunchKernelGGL(k_gn_update, g, b, 0, s, p->pd, -1);
     HC(hipMemsetAsync(p->pd.costred + NSHARD, 0, NSHARD * sizeof(double), s));
     hipLaunchKernelGGL(k_cost, g, b, 0, s, p->pd, 1);
     const double newCost = plan_read_cost(p, 0, 1);
@@ -1608,6 +1634,7 @@ ArapFlow_Solver* ArapFlow_SolverCreate(Opt_State* st, unsigned W, unsigned H, un
     s->plan = plan_create(st, (int)W, (int)H, (int)batch);
     plan_enable_resident(s->plan);
     s->plan->res_frames = s->plan->res_capable;
+    s->plan->res_frames_any = true;
     s->plan->grid_u = true;                                   // k_frame_reset writes U = the pixel grid
     {
         const size_t T = (size_t)s->plan->pd.tilesX * s->plan->pd.tilesY;
@@ -1908,6 +1935,7 @@ int ArapFlow_SolverResidentLayout(ArapFlow_Solver* s, int* launches_per_step, in
     return 0;
 }
 int ArapFlow_ResidentFailed(Opt_State* state) { return state && state->resident_failed ? 1 : 0; }
+int ArapFlow_SolverLeanStream(ArapFlow_Solver* s) { return s && plan_lean_stream(s->plan) ? 1 : 0; }
 
 // diagnostic (ARAPOPT_STAMPS=1): copy the [256][8] phase-time table of the LAST resident launch
 int ArapFlow_SolverStamps(ArapFlow_Solver* s, uint64_t* out)

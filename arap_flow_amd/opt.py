@@ -367,7 +367,8 @@ class FrameSolver:
         self.lib.ArapFlow_SolverResidentLayout(self.h, C.byref(ls), C.byref(fl))
         return dict(pcg_iterations_per_frame=a.value, active_vertices=b.value, grid_vertices=c.value,
                     resident_launches=int(self.lib.ArapFlow_SolverResidentLaunches(self.h)),
-                    resident_launches_per_step=ls.value, resident_solves_in_flight=fl.value)
+                    resident_launches_per_step=ls.value, resident_solves_in_flight=fl.value,
+                    lean_stream=bool(self.lib.ArapFlow_SolverLeanStream(self.h)))
 
     def close(self):
         if self.h:

@@ -369,19 +369,28 @@ def main():
                 kname = "k_pcg_resident"
             else:
                 per = {}
-                for k, bytes_v in (("PCGStepA", BYTES_A), ("PCGStepB", BYTES_B)):
+                # algorithmic bytes per vertex of each phase: SURVEY 8(d)'s split (64 + 96); the lean streaming schedule
+                # moves z's and one p's traffic away and delta into phase A: 85 + 41 (arap_stream.h)
+                lean = bool(fs.stats().get("lean_stream"))
+                bytes_ab = (85, 41) if lean else (BYTES_A, BYTES_B)
+                for k, bytes_v in (("PCGStepA", bytes_ab[0]), ("PCGStepB", bytes_ab[1])):
                     tot_ms, n = kt[k]
                     avg_s = tot_ms / n * 1e-3
                     per[k] = {"avg_us": avg_s * 1e6, "launches": n, "GBs_active": bytes_v * n_act_total / avg_s / 1e9,
                               "GBs_grid": bytes_v * n_grid * B / avg_s / 1e9}
                 dom = max(per, key=lambda k: per[k]["avg_us"])
                 kname = {"PCGStepA": "k_pcg_a", "PCGStepB": "k_pcg_b"}[dom]
-                rl = {"bound": "hbm", "kernel": kname,
+                t_it = (per["PCGStepA"]["avg_us"] + per["PCGStepB"]["avg_us"]) * 1e-6
+                iteration = {"us": t_it * 1e6, "GBs_survey_160B": 160.0 * n_act_total / t_it / 1e9,
+                             "frac_survey_160B": 160.0 * n_act_total / t_it / 1e9 / HBM_PEAK_GBS,
+                             "schedule": "lean (k_pcg_a_march2 + k_pcg_b4_r)" if lean else "k_pcg_a_march + k_pcg_b4_lean"}
+                rl = {"bound": "hbm", "kernel": kname, "iteration": iteration,
                       "achieved": per[dom]["GBs_active"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": per[dom]["GBs_active"] / HBM_PEAK_GBS, "traffic": None,
                       "avg_launch_us": per[dom]["avg_us"], "achieved_vs_grid_vertices": per[dom]["GBs_grid"],
                       "frac_vs_grid_vertices": per[dom]["GBs_grid"] / HBM_PEAK_GBS, "per_kernel": per,
-                      "note": "algorithmic bytes = %d (A) / %d (B) per active vertex per launch" % (BYTES_A, BYTES_B)}
+                      "note": "algorithmic bytes = %d (A) / %d (B) per active vertex per launch; `iteration` = SURVEY 8(d)'s "
+                              "160 B per vertex over the two launches of one PCG iteration" % bytes_ab}
             # counters of the same workload from rocprofv3 passes (collected separately: tools/collect_profile.py)
             rl["hbm_frac_by_counters"] = rl["valu_issue_frac"] = rl["wait_frac"] = None
             rl["valu_frac_of_ceiling"] = rl["lds_frac"] = None

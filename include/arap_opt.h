@@ -239,6 +239,10 @@ uint64_t ArapFlow_PlanResidentLaunches(Opt_Plan* plan);
  * two-kernel path (same results) and the resident path pauses for the next 8 solve calls (doubling with every
  * further timeout, up to 1024; a checked success resets it).  Returns 1 once any launch of this state has given up. */
 int ArapFlow_ResidentFailed(Opt_State* state);
+/* 1 if the batch of the last solve call, where it runs kernel per phase (solves the resident kernel cannot hold, or a
+ * pause after a timeout), takes the lean streaming schedule (arap_stream.h: k_pcg_a_march2 / k_pcg_b4_r: 85 + 41 bytes
+ * per vertex and iteration instead of 57 + 89), which it does when most of its tiles are active. */
+int ArapFlow_SolverLeanStream(ArapFlow_Solver* s);
 /* Diagnostic only (env ARAPOPT_STAMPS=1 selects an instrumented build of the resident kernel): copies
  * out[512][16] = per workgroup {phase A, wait 1, phase B, wait 2, update} summed 100 MHz ticks of the
  * last resident launch, tiles per workgroup, halo cells.  Returns -1 when stamps are off. */

@@ -57,27 +57,28 @@ def load_cat512(golden_dir):
 
 def t4_bands(golden_dir):
     """Tier T4 acceptance bands from the committed calibration table tests/golden/t4_variants.json (made by
-    tests/golden/make_t4_variants.py): eight arithmetic variants of the CPU oracle (f32 / f64, sequential / float64
-    sums, libm / spec trig, fused multiply-adds on / off) and six runs of the product's arithmetic from an initial
-    Angle perturbed by N(0, 1e-6 rad), all on the reference's cat512 fixture, full 19/8/400 schedule.  Every one of
-    them is a correct evaluation of the reference's algorithm; the bands are what THEY span (the product's own row is
-    left out, so the band is not drawn around the value under test):
-      cost      : mean +- 3 standard deviations of the other trajectories' final costs (they scatter over 55.8 .. 61.1
-                  with a standard deviation of ~2: the final cost of this unconverged schedule is itself a random
-                  variable of the rounding trajectory; a 1e-6 rad perturbation of the start moves it by 6 %)
-      rel_l2    : 1.1 x the largest rel-L2 to the reference golden among the other trajectories
+    tests/golden/make_t4_variants.py): 39 trajectories besides the product's own -- seven other arithmetic variants of
+    the CPU oracle (f32 / f64, sequential / float64 sums, libm / spec trig, fused multiply-adds on / off), 20 runs of the
+    product's arithmetic and 12 of f32_sum64_libm_nofma from an initial Angle perturbed by N(0, 1e-6 rad), all on the
+    reference's cat512 fixture, full 19/8/400 schedule.  Every one of them is a correct evaluation of the reference's
+    algorithm; the bands are EMPIRICAL: what those 39 span, widened by 10 % (the product's own row is left out, so no band
+    is drawn around the value under test):
+      cost      : [0.9 x smallest, 1.1 x largest] final cost (they scatter over 52.9 .. 63.4, mean 58.7, standard
+                  deviation 2.4: the final cost of this unconverged schedule is a random variable of the rounding
+                  trajectory; a 1e-6 rad perturbation of the start moves it by up to 13 %)
+      rel_l2    : 1.1 x the largest rel-L2 to the reference golden (0.0117; 7 of the 39 exceed SURVEY 8c's 1e-2)
       median_px : 1.1 x their largest median error
-      handle_px : 2e-4 px, SURVEY 8c's bound (the product measures 1.8e-4; two other correct trajectories of the table
-                  sit at 2.1e-4 and 7.6e-4, so this bound is the tightest the algorithm's own scatter allows)"""
+      handle_px : 2e-4 px, SURVEY 8c's bound (the product measures 1.8e-4; 10 of the 39 correct trajectories sit at
+                  2.1e-4 .. 7.6e-4, so this bound is as tight as the algorithm's own scatter allows)"""
     import json
     import os
     tab = json.load(open(os.path.join(golden_dir, "t4_variants.json")))
     others = [v for k, v in tab["variants"].items() if k != tab["product_variant"]]
-    others += list(tab.get("perturbed_starts_product_arithmetic", {}).values())
+    for key in tab:
+        if key.startswith("perturbed_starts_"):
+            others += list(tab[key].values())
     costs = [v["final_cost"] for v in others]
-    import numpy as _np
-    mu, sd = float(_np.mean(costs)), float(_np.std(costs, ddof=1))
-    return dict(cost=(mu - 3.0 * sd, mu + 3.0 * sd),
+    return dict(cost=(0.9 * min(costs), 1.1 * max(costs)),
                 rel_l2=1.1 * max(v["rel_l2_vs_golden"] for v in others),
                 median_px=1.1 * max(v["median_px_vs_golden"] for v in others),
-                handle_px=2e-4, quads=5, table=tab)
+                handle_px=2e-4, quads=5, table=tab, n=len(others))
