@@ -1,11 +1,11 @@
 """Markdown table of the records under profiles/ (what DESIGN.md §4 "Other configurations" quotes):
-    python tools/summarize_profiles.py [round]      (default r02)"""
+    python tools/summarize_profiles.py [round]      (default r03)"""
 import json
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 names = ["davis_854x480", "multseg3_fd2_854x480", "full_854x480", "multseg3_fd5_1920x1080", "full_1920x1080"]
 print("| configuration | frames/s | kernel | rocprof avg launch | µs / PCG iteration | frac (§8d, 8 TB/s) | HBM by counters | "
       "VALU issue | wait share | parity_check | CPU oracle (16 thr) |")
