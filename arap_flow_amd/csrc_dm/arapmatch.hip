@@ -151,9 +151,13 @@ __global__ __launch_bounds__(256) void k_corr0(const float* __restrict__ d1, con
             dst[idx] = (yin && x >= 0 && x < w) ? d2[((size_t)y * w + x) * NCH + c] : 0.f;
         }
     };
-    for (int b = 0; b < 3; ++b) load_row(4 * j - r + b);
+    // the vertical displacements are split over gridDim.z workgroups (two per patch row: two wavefronts per SIMD, so that
+    // one's LDS reads and epilogue stores hide behind the other's MFMAs)
+    const int per = (S + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int dy0 = -r + (int)blockIdx.z * per, dy1 = min(r, dy0 + per - 1);
+    for (int b = 0; b < 3; ++b) load_row(4 * j + dy0 + b);
     const int ntiles = (NP + 31) / 32;
-    for (int dy = -r; dy <= r; ++dy) {
+    for (int dy = dy0; dy <= dy1; ++dy) {
         load_row(4 * j + dy + 3);
         __syncthreads();
         int rowoff[4];                                               // ring offset of the patch row b under this dy
@@ -162,15 +166,18 @@ __global__ __launch_bounds__(256) void k_corr0(const float* __restrict__ d1, con
         for (int nt = wave; nt < ntiles; nt += 4) {
             const int p = nt * 32 + m;                               // this lane's placement (B column)
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // the 72 B values of this lane first (all LDS reads in flight together), then 72 MFMAs back to back
+            float breg[KDIM / 2];
 #pragma unroll
             for (int s = 0; s < KDIM / 2; ++s) {
                 // B[k][n] = frame 2 at (row b, pixel p + a, channel c), k = (4 b + a) 9 + c: compile-time for either half of the lanes
                 const int k0 = 2 * s, pix0 = k0 / NCH, c0 = k0 - pix0 * NCH, b0 = pix0 >> 2, a0 = pix0 & 3;
                 const int k1 = 2 * s + 1, pix1 = k1 / NCH, c1 = k1 - pix1 * NCH, b1 = pix1 >> 2, a1 = pix1 & 3;
                 const int o0 = rowoff[b0] + (p + a0) * NCH + c0, o1 = rowoff[b1] + (p + a1) * NCH + c1;
-                const float bv = (p < NP) ? ring[kk ? o1 : o0] : 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], bv, acc, 0, 0, 0);
+                breg[s] = (p < NP) ? ring[kk ? o1 : o0] : 0.f;
             }
+#pragma unroll
+            for (int s = 0; s < KDIM / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[s], breg[s], acc, 0, 0, 0);
             // C: lane l holds column l & 31, rows (v & 3) + 8 (v >> 2) + 4 (l >> 5) in register v
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -424,7 +431,7 @@ int ArapMatch_Run(ArapMatch* m, const uint8_t* rgb1, const uint8_t* rgb2, float*
     describe(m, rgb2, 1);
     const Level& L0 = m->lv[0];
     const int gh = L0.nh, gw = L0.nw;
-    hipLaunchKernelGGL(k_corr0, dim3((gw + 31) / 32, gh), dim3(256), m->corr_lds, s, m->desc[0], m->desc[1], L0.maps, m->h, m->w,
+    hipLaunchKernelGGL(k_corr0, dim3((gw + 31) / 32, gh, 2), dim3(256), m->corr_lds, s, m->desc[0], m->desc[1], L0.maps, m->h, m->w,
                        gh, gw, m->r);
     for (size_t l = 1; l < m->lv.size(); ++l) {
         const Level& b = m->lv[l - 1];

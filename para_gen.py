@@ -54,6 +54,12 @@ flow_dir, wrgb_dir, wMask_dir = "Flow", "wRGB", "wMasks"
 CPP_BIN = osp.join(HERE, "arap_flow_amd", "bin", "arap_deform")
 
 
+def _pair_id(seq, stem):
+    """a number per frame pair that is the same in every process and every run (str hashes are salted per process)"""
+    import zlib
+    return zlib.crc32(("%s/%s" % (seq, stem)).encode())
+
+
 def run_matching(flags, p, seq, stem):
     """para_gen.py:227-240, or precomputed matches"""
     for k in ("rgb1_org", "rgb2_org", "msk1_org", "msk2_org"):
@@ -68,7 +74,7 @@ def run_matching(flags, p, seq, stem):
         # inputs, same -ngh_rad, same output file format as the binary below
         from arap_flow_amd import match_server
         socks = flags.dm_sockets
-        match_server.request(socks[hash((seq, stem)) % len(socks)], p["rgb1_org"], p["rgb2_org"], p["cstr_tmp"], 100)
+        match_server.request(socks[_pair_id(seq, stem) % len(socks)], p["rgb1_org"], p["rgb2_org"], p["cstr_tmp"], 100)
         return
     cmd = "./%s %s %s -nt 0 -out %s -ngh_rad 100 " % (flags.dm_bin, p["rgb1_org"], p["rgb2_org"], p["cstr_tmp"])
     status = subprocess.call(cmd, shell=True)
@@ -137,7 +143,7 @@ def prepare_pair(args):
         except Exception:
             bgim = None
     if bgim is not None:
-        bgim = pipeline.fit_bg(bgim, im1, rng=rn.Random(hash((seq, stem)) & 0xffffffff))
+        bgim = pipeline.fit_bg(bgim, im1, rng=rn.Random(_pair_id(seq, stem)))
         out1 = pipeline.add_bg(im1, mk1, bgim)
     else:
         out1 = im1

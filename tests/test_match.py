@@ -141,3 +141,34 @@ def test_hip_matcher_recovers_a_translation_at_854x480():
     assert 0 < ms < 500.0
     print("matcher 854x480: %d matches, %.2f ms on the GPU" % (len(m), ms))
     mt.close()
+
+
+def test_c_program_against_the_match_header_links_with_the_library(tmp_path):
+    """include/arap_match.h is plain C and libarapmatch.so links from C: the boundary a maintainer binds in place of the
+    DeepMatching process (run here it gets NULL from ArapMatch_Create: no HIP device, no CPU fallback)"""
+    import subprocess
+    from arap_flow_amd import build
+    lib = build.build_match()
+    src = tmp_path / "m.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "arap_match.h"
+int main(void)
+{
+    ArapMatch* m = ArapMatch_Create(854, 480, 100);
+    if (!m) { printf("no matcher\n"); return 0; }
+    unsigned char* a = calloc(854 * 480 * 3, 1);
+    float* out = malloc(8192 * 6 * sizeof(float));
+    int n = ArapMatch_Run(m, a, a, out, 8192);
+    printf("%d matches, %d levels, %.2f ms\n", n, ArapMatch_Levels(m), ArapMatch_LastRunMs(m));
+    ArapMatch_Free(m);
+    return 0;
+}
+''')
+    exe = tmp_path / "m"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L" + os.path.dirname(lib), "-larapmatch", "-Wl,-rpath," + os.path.dirname(lib),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and ("no matcher" in r.stdout or "matches" in r.stdout), r.stdout + r.stderr
