@@ -1,0 +1,10 @@
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29533")
+os.environ["RANK"]="0"; os.environ["WORLD_SIZE"]="1"; os.environ["LOCAL_RANK"]="0"
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda",0))
+dist.barrier()
+t=torch.tensor([1.25],dtype=torch.float64,device="cuda"); dist.all_reduce(t,op=dist.ReduceOp.MAX)
+g=[torch.zeros_like(t) for _ in range(1)]; dist.all_gather(g,t)
+print("rccl ok", float(t.item()), float(g[0].item()), dist.get_world_size())
+dist.barrier(); dist.destroy_process_group()
