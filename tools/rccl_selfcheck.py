@@ -1,3 +1,6 @@
+"""GPU box: the torch.distributed (RCCL) calls bench.py makes for N > 1 -- init_process_group("nccl", device_id=...),
+barrier, all_reduce(MAX) of a float64 tensor, all_gather -- on a world of ONE rank, the most a 1-GPU box can run: checks
+that RCCL loads and those calls work on this image (the N = 8 run itself is the driver's).   python tools/rccl_selfcheck.py"""
 import os, torch, torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR","127.0.0.1"); os.environ.setdefault("MASTER_PORT","29533")
 os.environ["RANK"]="0"; os.environ["WORLD_SIZE"]="1"; os.environ["LOCAL_RANK"]="0"
