@@ -172,3 +172,23 @@ int main(void)
                            "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and ("no matcher" in r.stdout or "matches" in r.stdout), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_hip_matcher_on_the_reference_fixture_pair(golden_dir):
+    """The only real image pair the reference holds: cat512_iRGB.png and its warped counterpart cat512_wRGB.png, with the
+    dense flow between them known (cat512_iFlo.flo).  The deformation is strongly non-rigid (median displacement 47 px,
+    local stretch and rotation), far from what the matcher sees between neighbouring video frames; this is a sanity
+    anchor on real data, not a pin: of the matches that start on the object and whose true displacement is inside the
+    search radius, most land within 6 px of the known flow."""
+    import helpers
+    from arap_flow_amd import match
+    cat = helpers.load_cat512(golden_dir)
+    mt = match.Matcher(512, 512, 100)
+    m = mt.run(cat["rgb"], cat["golden_wrgb"])
+    mt.close()
+    x1, y1 = m[:, 0].astype(int), m[:, 1].astype(int)
+    g = cat["golden_flow"][y1, x1]
+    on = (cat["mask_red"][y1, x1] == 0) & (np.abs(g).max(-1) <= 96)
+    err = np.hypot(*((m[:, 2:4] - m[:, 0:2]) - g).T)
+    assert on.sum() > 500 and (err[on] <= 6).mean() >= 0.5 and np.median(err[on]) <= 6.0, (on.sum(), (err[on] <= 6).mean(), np.median(err[on]))
