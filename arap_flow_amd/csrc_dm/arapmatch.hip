@@ -325,7 +325,7 @@ using namespace dm;
 struct ArapMatch {
     int W, H, w, h, r;
     hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, c0 = nullptr, c1 = nullptr;     // whole Run; k_corr0 alone
     uint8_t* d_rgb = nullptr;             // one frame at a time
     float *gray = nullptr, *t0 = nullptr, *t1 = nullptr, *ori = nullptr, *ori2 = nullptr;
     float* desc[2] = {nullptr, nullptr};
@@ -335,7 +335,7 @@ struct ArapMatch {
     float* rows = nullptr;
     std::vector<float> hrows;
     int bw = 0, bh = 0;
-    float last_ms = 0.f;
+    float last_ms = 0.f, last_corr_ms = 0.f;
     size_t corr_lds = 0;
 };
 
@@ -375,6 +375,8 @@ ArapMatch* ArapMatch_Create(unsigned W, unsigned H, unsigned ngh_rad)
     HC(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     HC(hipEventCreate(&m->e0));
     HC(hipEventCreate(&m->e1));
+    HC(hipEventCreate(&m->c0));
+    HC(hipEventCreate(&m->c1));
     const size_t n = (size_t)m->h * m->w;
     HC(hipMalloc(&m->d_rgb, (size_t)W * H * 3));
     HC(hipMalloc(&m->gray, n * 4)); HC(hipMalloc(&m->t0, n * 4)); HC(hipMalloc(&m->t1, n * 4));
@@ -417,7 +419,7 @@ void ArapMatch_Free(ArapMatch* m)
     (void)hipFree(m->d_rgb); (void)hipFree(m->gray); (void)hipFree(m->t0); (void)hipFree(m->t1);
     (void)hipFree(m->ori); (void)hipFree(m->ori2); (void)hipFree(m->desc[0]); (void)hipFree(m->desc[1]);
     (void)hipFree(m->ent[0]); (void)hipFree(m->ent[1]); (void)hipFree(m->best); (void)hipFree(m->bins); (void)hipFree(m->rows);
-    (void)hipEventDestroy(m->e0); (void)hipEventDestroy(m->e1);
+    (void)hipEventDestroy(m->e0); (void)hipEventDestroy(m->e1); (void)hipEventDestroy(m->c0); (void)hipEventDestroy(m->c1);
     (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -431,8 +433,10 @@ int ArapMatch_Run(ArapMatch* m, const uint8_t* rgb1, const uint8_t* rgb2, float*
     describe(m, rgb2, 1);
     const Level& L0 = m->lv[0];
     const int gh = L0.nh, gw = L0.nw;
+    HC(hipEventRecord(m->c0, s));
     hipLaunchKernelGGL(k_corr0, dim3((gw + 31) / 32, gh, 2), dim3(256), m->corr_lds, s, m->desc[0], m->desc[1], L0.maps, m->h, m->w,
                        gh, gw, m->r);
+    HC(hipEventRecord(m->c1, s));
     for (size_t l = 1; l < m->lv.size(); ++l) {
         const Level& b = m->lv[l - 1];
         const Level& t = m->lv[l];
@@ -460,6 +464,7 @@ int ArapMatch_Run(ArapMatch* m, const uint8_t* rgb1, const uint8_t* rgb2, float*
     HC(hipEventRecord(m->e1, s));
     HC(hipStreamSynchronize(s));
     HC(hipEventElapsedTime(&m->last_ms, m->e0, m->e1));
+    HC(hipEventElapsedTime(&m->last_corr_ms, m->c0, m->c1));
     unsigned cnt = 0;
     for (size_t p = 0; p < n0; ++p) {
         const float* rr = m->hrows.data() + p * 6;
@@ -504,5 +509,6 @@ int ArapMatch_GetDescriptors(ArapMatch* m, int which, float* host)
 }
 
 float ArapMatch_LastRunMs(ArapMatch* m) { return m ? m->last_ms : -1.f; }
+float ArapMatch_LastCorrMs(ArapMatch* m) { return m ? m->last_corr_ms : -1.f; }
 
 }  // extern "C"

@@ -21,6 +21,7 @@ SYMBOLS = [
     ("ArapMatch_GetLevel", _I, [_VP, _I, _VP]),
     ("ArapMatch_GetDescriptors", _I, [_VP, _I, _VP]),
     ("ArapMatch_LastRunMs", C.c_float, [_VP]),
+    ("ArapMatch_LastCorrMs", C.c_float, [_VP]),
 ]
 _lib = None
 
@@ -63,6 +64,9 @@ class Matcher:
 
     def last_ms(self):
         return float(self.lib.ArapMatch_LastRunMs(self.h))
+
+    def last_corr_ms(self):
+        return float(self.lib.ArapMatch_LastCorrMs(self.h))
 
     def levels(self):
         out = []

@@ -43,6 +43,8 @@ int ArapMatch_GetLevel(ArapMatch* m, int level, float* host);
 int ArapMatch_GetDescriptors(ArapMatch* m, int which, float* host);
 /* device time of the last Run in milliseconds (HIP events on the matcher's stream) */
 float ArapMatch_LastRunMs(ArapMatch* m);
+/* ... and of its dominant kernel, the bottom-level correlation (k_corr0), alone */
+float ArapMatch_LastCorrMs(ArapMatch* m);
 
 #ifdef __cplusplus
 }

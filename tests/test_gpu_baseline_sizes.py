@@ -72,12 +72,14 @@ def test_full_mask_854x480_four_xcd_groups_vs_oracle(gpu_state, oracle):
 
 
 def test_multseg_1920x1080_two_xcd_groups_vs_oracle(gpu_state, oracle):
-    """configs[4]: 1920x1080 --multseg K=3 fd=5 (~900 tiles per segment -> groups of 128 workgroups on two XCDs),
-    4 frames = 12 segment solves in 3 launches per Gauss-Newton step."""
+    """configs[4]: 1920x1080 --multseg K=3 fd=5 (~700-900 tiles per segment: more than one XCD holds).  Every such solve
+    takes a home XCD plus a short piece in a bin it shares with other pieces (arapopt.hip: resident_deal; one-hop sums
+    with a short second run): 4 frames = 12 segment solves in at most 3 launches per Gauss-Newton step (whole pairs of XCDs
+    needed 3)."""
     W, H, sched = 1920, 1080, (1, 2, 40)
     solves = [sg for s in range(4) for sg in synth.segment_masks(synth.make_frame(W, H, seed=s, K=3, fd=5))]
     outs, st = _run_batch(gpu_state, W, H, solves, sched)
-    assert st["resident_launches"] > 0, st
+    assert st["resident_launches"] > 0 and 1 <= st["resident_launches_per_step"] <= 3, st
     _assert_bits(oracle, solves, outs, sched, what="1920x1080 multseg")
 
 
