@@ -30,6 +30,25 @@ from PIL import Image                   # noqa: E402
 from arap_flow_amd import pipeline, synth   # noqa: E402
 
 
+def make_moving_tree(d, pairs, W, H):
+    """pairs for the built-in matcher: textured frames, one elliptical object label; frame 2 = frame 1 moved by (dx, dy)"""
+    inp = os.path.join(d, "in")
+    rng = np.random.default_rng(0)
+    for n in range(pairs):
+        name = "seq%04d" % n
+        for sub in ("orgRGB", "orgMasks"):
+            os.makedirs(os.path.join(inp, sub, name))
+        big = np.clip(synth.make_rgb(W + 64, H + 64, n).astype(np.int32) + rng.integers(-40, 41, (H + 64, W + 64, 1)), 0, 255).astype(np.uint8)
+        yy, xx = np.mgrid[0:H + 64, 0:W + 64]
+        lab = (((xx - 32 - W / 2) / (W * 0.28)) ** 2 + ((yy - 32 - H / 2) / (H * 0.30)) ** 2 < 1.0).astype(np.uint8)
+        dx, dy = int(rng.integers(-9, 10)) or 3, int(rng.integers(-9, 10)) or -2
+        for k in range(2):
+            y0, x0 = 32 - k * dy, 32 - k * dx
+            Image.fromarray(big[y0:y0 + H, x0:x0 + W]).save(os.path.join(inp, "orgRGB", name, "%05d.png" % k))
+            Image.fromarray(lab[y0:y0 + H, x0:x0 + W]).save(os.path.join(inp, "orgMasks", name, "%05d.png" % k))
+    return inp
+
+
 def make_tree(d, pairs, W, H, K):
     """one two-frame sequence per pair (frame seed = pair index, DAVIS-shaped blob(s), lattice matches): both frames of
     a pair carry the same labels so that para_gen's match filter (same label at both ends, para_gen.py:216-223) keeps
@@ -77,6 +96,9 @@ def main():
     ap.add_argument("--standin", type=int, default=0, metavar="NGPU",
                     help="host capacity run: NGPU stand-in workers (no GPU), see the module docstring")
     ap.add_argument("--jobs", type=int, default=0)
+    ap.add_argument("--builtin-matcher", action="store_true",
+                    help="no precomputed matches: `para_gen.py --dm_bin builtin` (libarapmatch.so) on pairs whose second frame "
+                         "is the first moved by a few pixels (so that the matcher has something to find)")
     ap.add_argument("--multseg", action="store_true")
     ap.add_argument("--size", type=int, nargs=2, default=[854, 480])
     ap.add_argument("--out", default=None)
@@ -87,11 +109,19 @@ def main():
     rec = {"pairs": a.pairs, "size": [W, H], "multseg": bool(a.multseg)}
     try:
         t = time.time()
-        inp, mdir = make_tree(d, a.pairs, W, H, 3 if a.multseg else 1)
+        if a.builtin_matcher:
+            inp, mdir = make_moving_tree(d, a.pairs, W, H), None
+        else:
+            inp, mdir = make_tree(d, a.pairs, W, H, 3 if a.multseg else 1)
         rec["tree_seconds"] = time.time() - t
         out = os.path.join(d, "out")
         cmd = [sys.executable, os.path.join(ROOT, "para_gen.py"), "--input", inp, "--output", out, "--gpu", "0",
-               "--matches", mdir] + (["--multseg"] if a.multseg else [])
+               "--matches", str(mdir)] + (["--multseg"] if a.multseg else [])
+        if a.builtin_matcher:
+            cmd = [sys.executable, os.path.join(ROOT, "para_gen.py"), "--input", inp, "--output", out, "--gpu", "0",
+                   "--dm_bin", "builtin"]
+            a.skip_list_mode = True
+            rec["matcher"] = "builtin (libarapmatch.so), two phases: match all pairs, then solve"
         if a.standin:
             fake = os.path.join(d, "standin_worker.py")
             open(fake, "w").write(STANDIN % ROOT)
