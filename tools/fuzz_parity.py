@@ -79,6 +79,16 @@ for it in range(N):
                 diverged += 1
                 nans += 1
                 continue
+            # ... and a solve that has blown up but is still finite (cost per active vertex beyond anything a mesh of this
+            # size can mean: offsets of hundreds of pixels on a frame a few pixels wide) is garbage too: its float64 sums
+            # span so many binades that their rounding depends on the order of summation, which differs between the
+            # paths (each path is deterministic; tools/fuzz_case.py 42 6 long: costs 4e7 / 2e15)
+            act = max(1, int((m == 0).sum()))
+            if min(a["cost"], t["cost"]) / act > 1e3:
+                diverged += 1
+                nans += 1
+                print("diverged (finite) it", it, "W,H", W, H, "slot", b, "costs", a["cost"], t["cost"], "active", act)
+                continue
             why = ("resident != two-kernel: non-finite floats %d / %d, finite in both %d of which differ %d"
                    % (int((~fa).sum()), int((~ft).sum()), int(both.sum()), ndiff))
         if ok and W * H <= 40000:
