@@ -186,8 +186,14 @@ __device__ __forceinline__ float keep_if(unsigned f, float v)
     return __uint_as_float(__float_as_uint(v) & (unsigned)m);
 }
 
+// block_sum8 (below) leaves a workgroup's sum in lanes 2 and 3 of wave 0; the same value in every lane:
+__device__ __forceinline__ double block_sum_uniform(double t)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), 3), __builtin_amdgcn_readlane(__double2loint(t), 3));
+}
+
 // Group-wide sum of one double per workgroup.  `part` is this workgroup's partial (valid in wave 0,
-// lane 0).  Wave 0 publishes it as two {tag, 32 bits} granules and sweeps the group's granules until
+// lanes 2 and 3: block_sum8).  Wave 0 publishes it as two {tag, 32 bits} granules and sweeps the group's granules until
 // every tag equals `epoch`; lane k owns workgroups k, k+64, ... and adds their partials in that order,
 // then the fixed DPP tree above adds the lanes, so every workgroup of the group computes the same bits.
 // Returns the sum rounded to float in every thread; false on timeout.
@@ -202,18 +208,17 @@ __device__ __forceinline__ bool group_sum(double part, unsigned epoch, unsigned 
         // the whole group waits for the slowest publisher: this wave's few instructions go first on its SIMD
         __builtin_amdgcn_s_setprio(3);
         unsigned long long* buf = gran_group + (size_t)(epoch & 1u) * wgs * RES_GS;
-        // lane 0 holds the partial: v_readfirstlane (a __shfl would be two ds_bpermute round trips)
-        part = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(part)),
-                                __builtin_amdgcn_readfirstlane(__double2loint(part)));
-        if (lane < 2) {
+        // lanes 2 and 3 hold the partial (block_sum8) and publish one half each: nothing between the sum and the stores
+        if ((lane >> 1) == 1) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(part);
-            const unsigned hw = lane == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+            const unsigned hw = lane == 2 ? (unsigned)bits : (unsigned)(bits >> 32);
             const unsigned long long gv = ((unsigned long long)epoch << 32) | hw;
             if (fast)
-                __hip_atomic_store(buf + rank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(buf + rank * RES_GS + (lane - 2), gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else
-                __hip_atomic_store(buf + rank * RES_GS + lane, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(buf + rank * RES_GS + (lane - 2), gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        part = block_sum_uniform(part);                // (for the sweep: this workgroup's own partial, in whichever lane)
         double v = 0.0;
         bool ok = false;
         if (tm) { c1 = __builtin_amdgcn_s_memtime(); tm[0] += c1 - c0; c0 = c1; }
@@ -400,17 +405,23 @@ __device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigne
     return bc.y != 0.0f;
 }
 
-// block-wide sum of a double over the 4 wavefronts; result valid in wave 0 lane 0
+// block-wide sum of a double over the 4 wavefronts; result valid in LANES 2 AND 3 of wave 0 (the lanes that publish
+// it, group_sum).  Lane k of wave 0 reads the sums of wavefronts k & 3 and (k & 3) ^ 1 -- two independent ds_read_b64, four
+// VGPRs -- adds them (lanes 0, 1: w0 + w1; lanes 2, 3: w2 + w3; the same bits in both lanes of a pair) and one DPP step
+// (row_shr:2) makes (w2 + w3) + (w0 + w1) in lanes 2 and 3.  (Lane 0 reading all four took two ds_read2_b64 into eight
+// VGPRs and four dependent additions; with fewer registers to spare the compiler issued the second read after the first
+// had returned: one more LDS round trip on the critical path of every group sum, 2 % of the run.)
 __device__ __forceinline__ double block_sum8(double v, double* wsum /* LDS, 4 doubles */)
 {
+    static_assert(RES_THREADS / 64 == 4, "one pair sum and one DPP step add four wavefronts");
     v = wave_sum_l63(v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 63) wsum[wave] = v;
     __syncthreads();
     double t = 0.0;
-    if (wave == 0 && lane == 0) {
-#pragma unroll
-        for (int w = 0; w < RES_THREADS / 64; ++w) t += wsum[w];
+    if (wave == 0) {
+        const double a = wsum[lane & 3], b = wsum[(lane & 3) ^ 1];
+        t = dpp_add_f64<0x112, 0xf>(a + b);
     }
     return t;
 }
@@ -515,54 +526,70 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #define TPA(T) ((T) + 4 * LPLANE)
 
     // ---- prologue: load state, p0 and cos/sin with halos ------------------------------------------
+    // Two memory round trips for all slots together: the tile origins, then everything else.  A vertex's flags and data
+    // are fetched side by side and the data dropped if the vertex turns out excluded (flags -> branch -> data, slot after
+    // slot, was 2 x NS dependent round trips: 33 us of every launch at 7 slots).
+    int org_[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) org_[j] = j < tp ? tl[tfirst + j] : -1;
+    float2 qP[NS], qC[NS], qR[NS], vP[NS], vC[NS], hP[NS], hC[NS];
+    float qA[NS], qRa[NS], qM[NS], vA[NS], hA[NS];
+    unsigned qF[NS], vF[NS], hF[NS];                   // flags of the own vertex / of the halo vertices this lane fetches
+    const int vrow = ly == 0 ? 0 : RT_Y + 1, hcol = lx == 0 ? 0 : RT_X + 1;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        const int k = j;                               // local tile
-        const int gt = tfirst + k;                     // position in the frame's active-tile list
-        rx[j] = ry[j] = ra[j] = 0.f; dx_[j] = dy_[j] = da_[j] = 0.f;
-        apx[j] = apy[j] = apa[j] = 0.f;
-        unsigned f = 0;
-        float mA = 0.f;
-        int x0 = -1, y0 = -1;
-        if (k < tp) {
-            const int org = tl[gt];
-            y0 = org / W; x0 = org - y0 * W;
-            const int x = x0 + lx, y = y0 + ly;
-            float* T = lds + k * LTILE;
-            if (x < W && y < H) {
-                const int i = x + W * y;
-                // Only ACTIVE vertices enter LDS; every other cell keeps the zero written above (k_gn_init leaves
-                // p0 of excluded vertices untouched and their cos/sin come from whatever Angle the caller holds:
-                // phase A multiplies such neighbours by a zero weight, so they must be finite).
-                f = pd.flags[gb + i];
-                if (f & F_ACT) {
-                    TP2(T)[cell] = pd.pO0[gb + i];
-                    TCS(T)[cell] = pd.cs[gb + i];
-                    TPA(T)[cell] = pd.pA0[gb + i];
-                    const float2 r = pd.rO[gb + i];
-                    rx[j] = r.x; ry[j] = r.y; ra[j] = pd.rA[gb + i];
-                    mA = pd.preA[gb + i];
-                }
-                // halo cells this thread is responsible for
-                int hi = -1, hc = 0;
-                if (ly == 0 && y0 > 0) { hi = i - W; hc = 0 * LROW + (lx + 1); }
-                if (ly == RT_Y - 1 && y + 1 < H) { hi = i + W; hc = (RT_Y + 1) * LROW + (lx + 1); }
-                if (hi >= 0 && (pd.flags[gb + hi] & F_ACT)) {
-                    TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
-                }
-                hi = -1;
-                if (lx == 0 && x0 > 0) { hi = i - 1; hc = (ly + 1) * LROW + 0; }
-                if (lx == RT_X - 1 && x + 1 < W) { hi = i + 1; hc = (ly + 1) * LROW + (RT_X + 1); }
-                if (hi >= 0 && (pd.flags[gb + hi] & F_ACT)) {
-                    TP2(T)[hc] = pd.pO0[gb + hi]; TCS(T)[hc] = pd.cs[gb + hi]; TPA(T)[hc] = pd.pA0[gb + hi];
-                }
+        qP[j] = qC[j] = qR[j] = vP[j] = vC[j] = hP[j] = hC[j] = make_float2(0.f, 0.f);
+        qA[j] = qRa[j] = qM[j] = vA[j] = hA[j] = 0.f;
+        qF[j] = vF[j] = hF[j] = 0u;
+        const int org = org_[j];
+        const int y0 = org / W, x0 = org - y0 * W;
+        const int x = x0 + lx, y = y0 + ly;
+        if (org >= 0 && x < W && y < H) {
+            const size_t i = gb + (size_t)(x + W * y);
+            qF[j] = pd.flags[i];
+            qP[j] = pd.pO0[i]; qC[j] = pd.cs[i]; qA[j] = pd.pA0[i];
+            qR[j] = pd.rO[i]; qRa[j] = pd.rA[i]; qM[j] = pd.preA[i];
+            // halo cells this thread is responsible for: above / below its column, left / right of its row
+            if ((ly == 0 && y0 > 0) || (ly == RT_Y - 1 && y + 1 < H)) {
+                const size_t hi = ly == 0 ? i - W : i + W;
+                vF[j] = pd.flags[hi]; vP[j] = pd.pO0[hi]; vC[j] = pd.cs[hi]; vA[j] = pd.pA0[hi];
+            }
+            if ((lx == 0 && x0 > 0) || (lx == RT_X - 1 && x + 1 < W)) {
+                const size_t hi = lx == 0 ? i - 1 : i + 1;
+                hF[j] = pd.flags[hi]; hP[j] = pd.pO0[hi]; hC[j] = pd.cs[hi]; hA[j] = pd.pA0[hi];
             }
         }
-        fl[j] = f;
-        ma_[j] = mA;
+    }
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        dx_[j] = dy_[j] = da_[j] = 0.f;
+        apx[j] = apy[j] = apa[j] = 0.f;
+        const int org = org_[j];
+        int x0 = -1, y0 = -1;
+        if (org >= 0) { y0 = org / W; x0 = org - y0 * W; }
+        float* T = lds + j * LTILE;
+        // Only ACTIVE vertices enter LDS; every other cell keeps the zero written above (k_gn_init leaves p0 of
+        // excluded vertices untouched and their cos/sin come from whatever Angle the caller holds: phase A multiplies
+        // such neighbours by a zero weight, so they must be finite).
+        const bool act = (qF[j] & F_ACT) != 0u;
+        if (act) {
+            TP2(T)[cell] = qP[j];
+            TCS(T)[cell] = qC[j];
+            TPA(T)[cell] = qA[j];
+        }
+        rx[j] = act ? qR[j].x : 0.f; ry[j] = act ? qR[j].y : 0.f; ra[j] = act ? qRa[j] : 0.f;
+        ma_[j] = act ? qM[j] : 0.f;
+        if (vF[j] & F_ACT) {
+            const int hc = vrow * LROW + (lx + 1);
+            TP2(T)[hc] = vP[j]; TCS(T)[hc] = vC[j]; TPA(T)[hc] = vA[j];
+        }
+        if (hF[j] & F_ACT) {
+            const int hc = (ly + 1) * LROW + hcol;
+            TP2(T)[hc] = hP[j]; TCS(T)[hc] = hC[j]; TPA(T)[hc] = hA[j];
+        }
+        fl[j] = qF[j];
         ibase[j] = __builtin_amdgcn_readfirstlane(x0 + W * y0);        // uniform: vertex index of the tile origin
-        if (tid == 0) tbase[k] = make_int2(x0, y0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (tid == 0) tbase[j] = make_int2(x0, y0);
     }
     float rho = read_scalar(pd.red + ((size_t)b * pd.nslots + 0) * NSHARD);     // rho_0 from k_gn_init
     __syncthreads();
@@ -831,8 +858,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             const unsigned long long cb = STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
             const double bs = block_sum8(acc, wsum);
             if (STAMPS) tbs += __builtin_amdgcn_s_memtime() - cb;
-            alive = hierx ? group_sum_x(bs, 2u * l + 2u, gran_group, granx_group, rank, wgs, bcast, rd.err, sigma, subfast)
-                  : hier  ? group_sum_h(bs, 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
+            alive = hierx ? group_sum_x(block_sum_uniform(bs), 2u * l + 2u, gran_group, granx_group, rank, wgs, bcast, rd.err, sigma, subfast)
+                  : hier  ? group_sum_h(block_sum_uniform(bs), 2u * l + 2u, gran_group, gran2, rank, wgs, bcast, rd.err, sigma, subfast)
                           : group_sum(bs, 2u * l + 2u, gran_group, rank, wgs, bcast, rd.err, sigma, fast, nullptr, rd.nowait != 0,
                                       STAMPS ? tm : nullptr);
         }
@@ -894,8 +921,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
                     }
                 }
             }
-            alive = hierx ? group_sum_x(bs, 2u * l + 3u, gran_group, granx_group, rank, wgs, bcast, rd.err, rhoNew, subfast)
-                  : hier  ? group_sum_h(bs, 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
+            alive = hierx ? group_sum_x(block_sum_uniform(bs), 2u * l + 3u, gran_group, granx_group, rank, wgs, bcast, rd.err, rhoNew, subfast)
+                  : hier  ? group_sum_h(block_sum_uniform(bs), 2u * l + 3u, gran_group, gran2, rank, wgs, bcast, rd.err, rhoNew, subfast)
                           : group_sum(bs, 2u * l + 3u, gran_group, rank, wgs, bcast, rd.err, rhoNew, fast, nullptr, rd.nowait != 0,
                                       STAMPS ? tm : nullptr);
         }
