@@ -405,6 +405,20 @@ __device__ __forceinline__ bool group_sum_x(double part, unsigned epoch, unsigne
     return bc.y != 0.0f;
 }
 
+// Append `val` to the workgroup's halo list for every lane with `take`: the wavefront reserves its entries with ONE LDS
+// atomic and every taker writes at its rank among the takers.
+__device__ __forceinline__ void halo_append(bool take, unsigned short val, unsigned short* hlist, int* nhalo)
+{
+    const unsigned long long m = __ballot(take);
+    if (m == 0ull) return;                             // (uniform)
+    const int first = __builtin_ctzll(m);
+    int base = 0;
+    if ((int)(threadIdx.x & 63) == first) base = atomicAdd(nhalo, __popcll(m));
+    base = __builtin_amdgcn_readlane(base, first);
+    const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (take) hlist[base + before] = val;
+}
+
 // block-wide sum of a double over the 4 wavefronts; result valid in LANES 2 AND 3 of wave 0 (the lanes that publish
 // it, group_sum).  Lane k of wave 0 reads the sums of wavefronts k & 3 and (k & 3) ^ 1 -- two independent ds_read_b64, four
 // VGPRs -- adds them (lanes 0, 1: w0 + w1; lanes 2, 3: w2 + w3; the same bits in both lanes of a pair) and one DPP step
@@ -500,11 +514,6 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         if (tid < 16) nbits[tid] = 0u;
     }
 
-    // every cell of the halo'd tiles holds a finite value: cells outside the image or of unused slots are never
-    // written below, and phase A multiplies (not selects) the contributions of invalid edges by zero
-    for (int c = tid; c < NS * LTILE; c += RES_THREADS) lds[c] = 0.f;
-    __syncthreads();
-
     float rx[NS], ry[NS], ra[NS];
     float dx_[NS], dy_[NS], da_[NS];
     float apx[NS], apy[NS], apa[NS];
@@ -532,14 +541,19 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     int org_[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) org_[j] = j < tp ? tl[tfirst + j] : -1;
-    float2 qP[NS], qC[NS], qR[NS], vP[NS], vC[NS], hP[NS], hC[NS];
-    float qA[NS], qRa[NS], qM[NS], vA[NS], hA[NS];
+    // No granule of this workgroup's tiles may carry a tag from an earlier launch: tag 0 everywhere (write-through,
+    // whatever the placement); the stores travel while the loads below do, and are waited for before the first granule.
+    unsigned long long* const zx_b = rd.zx + (size_t)b * RES_MAX_TILES * RES_ZG;    // this solve's published border z
+    for (int c = tid; c < tp * RES_ZG; c += RES_THREADS)
+        __hip_atomic_store(zx_b + (size_t)tfirst * RES_ZG + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float2 qC[NS], qR[NS], vP[NS], vC[NS], hP[NS], hC[NS];
+    float qRa[NS], qM[NS], vA[NS], hA[NS];
     unsigned qF[NS], vF[NS], hF[NS];                   // flags of the own vertex / of the halo vertices this lane fetches
     const int vrow = ly == 0 ? 0 : RT_Y + 1, hcol = lx == 0 ? 0 : RT_X + 1;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        qP[j] = qC[j] = qR[j] = vP[j] = vC[j] = hP[j] = hC[j] = make_float2(0.f, 0.f);
-        qA[j] = qRa[j] = qM[j] = vA[j] = hA[j] = 0.f;
+        qC[j] = qR[j] = vP[j] = vC[j] = hP[j] = hC[j] = make_float2(0.f, 0.f);
+        qRa[j] = qM[j] = vA[j] = hA[j] = 0.f;
         qF[j] = vF[j] = hF[j] = 0u;
         const int org = org_[j];
         const int y0 = org / W, x0 = org - y0 * W;
@@ -547,7 +561,8 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         if (org >= 0 && x < W && y < H) {
             const size_t i = gb + (size_t)(x + W * y);
             qF[j] = pd.flags[i];
-            qP[j] = pd.pO0[i]; qC[j] = pd.cs[i]; qA[j] = pd.pA0[i];
+            // (own p0 = M^-1 r is formed below exactly as k_gn_init formed it: 12 bytes per vertex less to fetch)
+            qC[j] = pd.cs[i];
             qR[j] = pd.rO[i]; qRa[j] = pd.rA[i]; qM[j] = pd.preA[i];
             // halo cells this thread is responsible for: above / below its column, left / right of its row
             if ((ly == 0 && y0 > 0) || (ly == RT_Y - 1 && y + 1 < H)) {
@@ -560,6 +575,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             }
         }
     }
+    // every cell of the halo'd tiles holds a finite value: cells outside the image or of unused slots are never
+    // written below, and phase A multiplies (not selects) the contributions of invalid edges by zero
+    for (int c = tid; c < NS * LTILE; c += RES_THREADS) lds[c] = 0.f;
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         dx_[j] = dy_[j] = da_[j] = 0.f;
@@ -572,13 +591,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         // excluded vertices untouched and their cos/sin come from whatever Angle the caller holds: phase A multiplies
         // such neighbours by a zero weight, so they must be finite).
         const bool act = (qF[j] & F_ACT) != 0u;
-        if (act) {
-            TP2(T)[cell] = qP[j];
-            TCS(T)[cell] = qC[j];
-            TPA(T)[cell] = qA[j];
-        }
         rx[j] = act ? qR[j].x : 0.f; ry[j] = act ? qR[j].y : 0.f; ra[j] = act ? qRa[j] : 0.f;
         ma_[j] = act ? qM[j] : 0.f;
+        mo_[j] = moLUT[__popc(qF[j] & 15u) + 5 * (int)((qF[j] >> 4) & 1u)];      // M^-1 of the Offset components
+        if (act) {
+            TP2(T)[cell] = make_float2(mo_[j] * rx[j], mo_[j] * ry[j]);           // p0 = M^-1 r (k_gn_init)
+            TCS(T)[cell] = qC[j];
+            TPA(T)[cell] = ma_[j] * ra[j];
+        }
         if (vF[j] & F_ACT) {
             const int hc = vrow * LROW + (lx + 1);
             TP2(T)[hc] = vP[j]; TCS(T)[hc] = vC[j]; TPA(T)[hc] = vA[j];
@@ -597,7 +617,6 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const unsigned f = fl[j];
-        mo_[j] = moLUT[__popc(f & 15u) + 5 * (int)((f >> 4) & 1u)];      // M^-1 of the Offset components
         if (WREG) {
             if (NWR > 0) we[j][0] = keep_if<0>(f, wr2);
             if (NWR > 1) we[j][1] = keep_if<1>(f, wr2);
@@ -605,10 +624,11 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             if (NWR > 3) we[j][3] = keep_if<3>(f, wr2);
             if (NS <= RES_WREG_FIT) we[j][4] = keep_if<4>(f, wf2);
         }
-        if (ly == 0 && (f & F_E3)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + 0 * LROW + lx + 1);
-        if (ly == RT_Y - 1 && (f & F_E2)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (RT_Y + 1) * LROW + lx + 1);
-        if (lx == 0 && (f & F_E1)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (ly + 1) * LROW + 0);
-        if (lx == RT_X - 1 && (f & F_E0)) hlist[atomicAdd(nhalo, 1)] = (unsigned short)(j * LPLANE + (ly + 1) * LROW + RT_X + 1);
+        // (one LDS atomic per wavefront and kind, not one per entry: 560 atomics on one address took 2 us of every launch)
+        halo_append(ly == 0 && (f & F_E3), (unsigned short)(j * LPLANE + 0 * LROW + lx + 1), hlist, nhalo);
+        halo_append(ly == RT_Y - 1 && (f & F_E2), (unsigned short)(j * LPLANE + (RT_Y + 1) * LROW + lx + 1), hlist, nhalo);
+        halo_append(lx == 0 && (f & F_E1), (unsigned short)(j * LPLANE + (ly + 1) * LROW + 0), hlist, nhalo);
+        halo_append(lx == RT_X - 1 && (f & F_E0), (unsigned short)(j * LPLANE + (ly + 1) * LROW + RT_X + 1), hlist, nhalo);
     }
     __syncthreads();
     const int nh = *nhalo;
@@ -673,14 +693,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
             asm volatile("" : "+v"(offA[n]));
         }
     }
-    unsigned long long* const zx_b = rd.zx + (size_t)b * RES_MAX_TILES * RES_ZG;    // this solve's published border z
     const int zent = border_entry(lx, ly);             // this lane's entry in its tile's border export
     bool alive = true;
     float alpha_last = 0.f;                            // alpha of the last iteration (its delta update happens after the loop)
-    // No granule of this workgroup's tiles may carry a tag from an earlier launch: tag 0 everywhere (write-through,
-    // whatever the placement), landed before this workgroup's epoch-1 granule below -- which every reader waits for.
-    for (int c = tid; c < tp * RES_ZG; c += RES_THREADS)
-        __hip_atomic_store(zx_b + (size_t)tfirst * RES_ZG + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the tag-0 stores of the prologue have landed before this workgroup's epoch-1 granule below, which every reader waits for)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- do all workgroups of this group sit on one XCD?  (speed only: selects the store flavour) --------

@@ -17,7 +17,7 @@ P = out[512:, :9].astype(np.float64)
 used = P[:, 0] > 0
 P = P[used]
 t00 = P[:, 0].min()
-names = ["start(rel. to first WG)", "lds zero", "slot loads", "halo list", "decode table", "tag zero+drain", "xcc exchange", "neighbour check", "loop"]
+names = ["start(rel. to first WG)", "startup+issue loads", "lds zero+loads arrive", "halo list", "decode table", "drain", "xcc exchange", "neighbour check", "loop"]
 print("workgroups", used.sum(), " (100 MHz ticks -> us)")
 print("%-26s mean %.2f max %.2f" % (names[0], ((P[:, 0] - t00) * 0.01).mean(), ((P[:, 0] - t00) * 0.01).max()))
 for k in range(1, 9):
