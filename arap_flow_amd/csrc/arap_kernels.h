@@ -6,7 +6,7 @@
 //   k_gn_init    : PCGInit1 (:361-397)
 //   k_pcg_a      : PCGStep3 of the previous iteration (:537-550) fused with PCGStep1 (:421-434)
 //   k_pcg_b      : PCGStep2 (:446-489)
-//   k_gn_update  : PCGLinearUpdate (:552-557)
+//   k_gn_update  : PCGLinearUpdate (:552-557)    (k_gn_update_prep: ... and the next step's k_gn_prep, frame solver)
 //   k_cost       : computeCost (:580-592)
 // Launch shape: workgroup = 64 x 4 threads (4 wavefronts, each 64 consecutive x of one row),
 // grid = (ceil(W/64), ceil(H/4), batch); one thread per mesh vertex.
@@ -55,12 +55,16 @@ __device__ __forceinline__ VIdx vidx(const PlanDev& pd)
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
+// FLAGS = false: Mask and Constraints are as the last full pass saw them (between two steps of the frame solver): only
+// cos/sin of the new Angle and the zeroing are due
+template <bool FLAGS>
+__device__ __forceinline__ void gn_prep_body(const PlanDev& pd, const VIdx& v)
 {
-    const VIdx v = vidx(pd);
     const Slot sl = pd.slots[v.b];
     unsigned f = 0;
-    if (v.in) {
+    if (!FLAGS) {
+        if (v.in) pd.cs[v.g] = sincos_spec(sl.A[v.i]);
+    } else if (v.in) {
         const int W = pd.W, H = pd.H;
         const bool act = sl.M[v.i] == 0.0f;
         if (act) {
@@ -75,9 +79,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
         pd.flags[v.g] = (uint8_t)f;
         pd.cs[v.g] = sincos_spec(sl.A[v.i]);
     }
-    const int any = __syncthreads_or((int)(f & F_ACT));
-    if (v.tile_ok && threadIdx.x == 0 && threadIdx.y == 0)
-        pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
+    if (FLAGS) {
+        const int any = __syncthreads_or((int)(f & F_ACT));
+        if (v.tile_ok && threadIdx.x == 0 && threadIdx.y == 0)
+            pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
+    }
     if (pd.res_gran_n) {
         const int t = threadIdx.y * TILE_X + threadIdx.x;
         if (v.lb == 0 && t < NSHARD) pd.red[(size_t)v.b * pd.nslots * NSHARD + t] = 0.0;
@@ -85,6 +91,11 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
             for (int i = (int)v.lb * (TILE_X * TILE_Y) + t; i < pd.res_gran_n; i += (int)v.nlb * (TILE_X * TILE_Y))
                 pd.res_gran[i] = 0ull;
     }
+}
+
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
+{
+    gn_prep_body<true>(pd, vidx(pd));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -372,9 +383,8 @@ __global__ __launch_bounds__(256) void k_pcg_b4(PlanDev pd, int l)
 // PCGLinearUpdate: X += delta on non-excluded vertices
 // lag_l >= 0 (the lean streaming schedule, arap_stream.h): the delta images still lack the last PCG iteration's
 // update delta += alpha_l p_l (every other iteration's was made by phase A of the iteration after it): made here.
-__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd, int lag_l)
+__device__ __forceinline__ void gn_update_body(const PlanDev& pd, const VIdx& v, int lag_l)
 {
-    const VIdx v = vidx(pd);
     if (pd.res_err && *pd.res_err) return;          // the resident kernel gave up: leave X as it was (see PlanDev)
     if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) return;
     float alpha = 0.f;
@@ -400,6 +410,21 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd, int la
     o.y = o.y + d.y;
     sl.O[v.i] = o;
     sl.A[v.i] = sl.A[v.i] + da;
+}
+
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd, int lag_l)
+{
+    gn_update_body(pd, vidx(pd), lag_l);
+}
+
+// Frame solver on the resident path: the update of one Gauss-Newton step and the preparation of the next (cos/sin of the
+// new Angle, zeroed granules; the flags stand: Mask and Constraints change only with the ramp) in one pass over the active tiles -- every vertex's update feeds only its own
+// cos/sin.  (The drop-in path keeps them apart: its caller may change Mask / Constraints between two steps, Opt.h:58-66.)
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update_prep(PlanDev pd)
+{
+    const VIdx v = vidx(pd);
+    gn_update_body(pd, v, -1);
+    gn_prep_body<false>(pd, v);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -158,6 +158,7 @@ struct Opt_Plan {
     unsigned res_launches = 0;
     // drop-in (Opt_*) plans: result of the Init-time analysis (k_analyse) of the caller's Mask / UrShape
     bool opt_res_ok = false;
+    bool prep_done = false;         // the last enqueued step left flags / cos-sin / granules ready for the next (k_gn_update_prep)
     Slot opt_res_slot{};
     int* d_notgrid = nullptr;
     // "LMGPU" plans
@@ -840,8 +841,15 @@ static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
     }
 }
 
+// Frame solver on the resident path: the update kernel of a step also prepares the next step (k_gn_update_prep), so a
+// step is [init, resident launches, update + prep] and a lone k_gn_prep runs only where no step came before (the first
+// step after the ramp moved the constraints, or after a step on another path): Opt_Plan::prep_done.
+static bool plan_fused_prep(Opt_Plan* p) { return plan_resident_eligible(p) && p->res_frames; }
+
 // enqueue the kernels of one Gauss-Newton step (without the cost) on stream s
-static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
+// part: GN_STEP_ALL = prep, init, PCG, update;  GN_STEP_PREP = the lone prep;  GN_STEP_FUSED = init, PCG, update + prep
+enum { GN_STEP_ALL = 0, GN_STEP_PREP = 1, GN_STEP_FUSED = 2 };
+static void enqueue_gn_step(Opt_Plan* p, hipStream_t s, int part = GN_STEP_ALL)
 {
     const int L = p->sp.lIterations;
     const dim3 g = p->grid(), b = p->blk();
@@ -868,7 +876,8 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
         pd.t64n = pdl.t64n = p->d_t64n;
         gl = dim3((unsigned)maxn, 1, (unsigned)p->nb);
     }
-    LAUNCH(p, s, "GNPrep", k_gn_prep, gl, b, pd);
+    if (part != GN_STEP_FUSED) LAUNCH(p, s, "GNPrep", k_gn_prep, gl, b, pd);
+    if (part == GN_STEP_PREP) return;
     LAUNCH(p, s, "PCGInit1", k_gn_init, gl, b, pdl);
     if (res) {
         // all L iterations in one launch, state on chip (arap_resident.h)
@@ -897,7 +906,8 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s)
     }
     // (the lean streaming schedule leaves the last iteration's delta += alpha p to the update kernel)
     const int lag = (!res && L > 0 && plan_lean_stream(p)) ? L - 1 : -1;
-    LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl, lag);
+    if (part == GN_STEP_FUSED) LAUNCH(p, s, "PCGLinearUpdate+GNPrep", k_gn_update_prep, gl, b, pd);
+    else LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl, lag);
 }
 
 static void plan_gn_step(Opt_Plan* p)
@@ -926,8 +936,12 @@ static void plan_gn_step(Opt_Plan* p)
         plan_drop_graph(p);
     }
     if (res) p->res_launches += (unsigned)p->res_sets;          // launches executed (graph replays included)
+    const bool fused = plan_fused_prep(p);
+    const int part = fused ? GN_STEP_FUSED : GN_STEP_ALL;
+    if (fused && !p->prep_done) enqueue_gn_step(p, st->stream, GN_STEP_PREP);
+    p->prep_done = fused;
     if (!graph_ok) {
-        enqueue_gn_step(p, st->stream);
+        enqueue_gn_step(p, st->stream, part);
         return;
     }
     // the captured launches bake in the path (resident: number of launches; two-kernel: phase-A variant)
@@ -939,7 +953,7 @@ static void plan_gn_step(Opt_Plan* p)
     if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now || p->g_maxn != maxn_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
-        enqueue_gn_step(p, st->cap);
+        enqueue_gn_step(p, st->cap, part);
         HC(hipStreamEndCapture(st->cap, &p->graph));
         HC(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
         p->g_l = p->sp.lIterations;
@@ -986,6 +1000,7 @@ static void plan_init(Opt_Plan* p)
 {
     HC(hipSetDevice(p->st->device));
     p->sp.nIter = 0;
+    p->prep_done = false;                  // the caller may have changed Mask / Constraints (the ramp does)
     plan_reserve(p, p->sp.lIterations, p->sp.nIterations + 1);
     plan_upload_slots(p);
     if (p->lazy_cost && !p->cost_wanted && p->st->verbosity == 0) return;
