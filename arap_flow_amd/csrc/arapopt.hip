@@ -147,6 +147,8 @@ struct Opt_Plan {
     std::vector<std::vector<int>> h_t64;
     std::vector<int> h_t64n;
     int g_maxn = -1;                // list length the captured graph was built for
+    int g_steps = 0;                // Gauss-Newton steps in the captured graph
+    unsigned long long g_ns = 0;    // ... and its resident launches' slot counts (hashed)
     int res_tiles_all = 0;          // 32x8 tiles of the whole grid (share of active tiles: plan_active_tiles_majority)
     bool hole_pending = false;      // test hook ARAPOPT_FORCE_RES_FAIL=2: the next table upload leaves one workgroup out
     ResWg* d_wgmap = nullptr;       // [batch][RES_WGS]: one table per resident launch of a GN step
@@ -846,6 +848,16 @@ static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
 // step after the ramp moved the constraints, or after a step on another path): Opt_Plan::prep_done.
 static bool plan_fused_prep(Opt_Plan* p) { return plan_resident_eligible(p) && p->res_frames; }
 
+// Grid of the list launches (k_gn_prep / k_gn_init / k_gn_update over the frames' active 64x4 tiles): the longest list,
+// rounded up to a multiple of 64 workgroups so that batches of similar frames replay the same captured graph (a
+// workgroup beyond its frame's list only reports a zero to the order-fixed sums).
+static int plan_list_blocks(Opt_Plan* p)
+{
+    int maxn = 1;
+    for (int k = 0; k < p->nb; ++k) maxn = std::max(maxn, p->h_t64n[k]);
+    return std::min((maxn + 63) / 64 * 64, p->pd.tilesX * p->pd.tilesY);
+}
+
 // enqueue the kernels of one Gauss-Newton step (without the cost) on stream s
 // part: GN_STEP_ALL = prep, init, PCG, update;  GN_STEP_PREP = the lone prep;  GN_STEP_FUSED = init, PCG, update + prep
 enum { GN_STEP_ALL = 0, GN_STEP_PREP = 1, GN_STEP_FUSED = 2 };
@@ -870,8 +882,7 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s, int part = GN_STEP_ALL)
     PlanDev pdl = p->pd;
     dim3 gl = g;
     if (lists) {
-        int maxn = 1;
-        for (int k = 0; k < p->nb; ++k) maxn = std::max(maxn, p->h_t64n[k]);
+        const int maxn = plan_list_blocks(p);
         pd.t64list = pdl.t64list = p->d_t64list;
         pd.t64n = pdl.t64n = p->d_t64n;
         gl = dim3((unsigned)maxn, 1, (unsigned)p->nb);
@@ -910,7 +921,9 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s, int part = GN_STEP_ALL)
     else LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl, lag);
 }
 
-static void plan_gn_step(Opt_Plan* p)
+// nsteps consecutive Gauss-Newton steps (one graph launch: between two graphs the GPU idles 8.6 us, inside one 0.2 us
+// per kernel boundary)
+static void plan_gn_step(Opt_Plan* p, int nsteps = 1)
 {
     Opt_State* st = p->st;
     const bool graph_ok = st->use_graph && !st->timing;
@@ -933,33 +946,39 @@ static void plan_gn_step(Opt_Plan* p)
             HC(hipMemcpyAsync(p->d_wgmap, p->pin_wgmap, p->h_wgmap.size() * sizeof(ResWg), hipMemcpyHostToDevice,
                               st->stream));
         }
-        plan_drop_graph(p);
+        // (the captured launches bake in only the number of launches, their slot counts and the list length: all part
+        //  of the graph's key below, so a new deal of the same shape replays the old graph)
     }
-    if (res) p->res_launches += (unsigned)p->res_sets;          // launches executed (graph replays included)
+    if (res) p->res_launches += (unsigned)(p->res_sets * nsteps);          // launches executed (graph replays included)
     const bool fused = plan_fused_prep(p);
     const int part = fused ? GN_STEP_FUSED : GN_STEP_ALL;
     if (fused && !p->prep_done) enqueue_gn_step(p, st->stream, GN_STEP_PREP);
     p->prep_done = fused;
     if (!graph_ok) {
-        enqueue_gn_step(p, st->stream, part);
+        for (int k = 0; k < nsteps; ++k) enqueue_gn_step(p, st->stream, part);
         return;
     }
     // the captured launches bake in the path (resident: number of launches; two-kernel: phase-A variant)
     const int res_now = res ? p->res_sets : -(2 + p->st->tile) - 8 * (int)(plan_active_tiles_majority(p)) - 16 * (int)p->grid_u -
                                             32 * (int)plan_lean_stream(p);
     int maxn_now = 0;
-    if (res && p->res_frames && p->d_t64list)
-        for (int k = 0; k < p->nb; ++k) maxn_now = std::max(maxn_now, p->h_t64n[k]);
-    if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now || p->g_maxn != maxn_now) {
+    if (res && p->res_frames && p->d_t64list) maxn_now = plan_list_blocks(p);
+    unsigned long long ns_now = 1469598103934665603ull;          // (FNV-1a over the launches' slot counts)
+    if (res)
+        for (int set = 0; set < p->res_sets; ++set) ns_now = (ns_now ^ (unsigned long long)p->res_ns[set]) * 1099511628211ull;
+    if (!p->gexec || p->g_l != p->sp.lIterations || p->g_nb != p->nb || p->g_res != res_now || p->g_maxn != maxn_now ||
+        p->g_steps != nsteps || p->g_ns != ns_now) {
         plan_drop_graph(p);
         HC(hipStreamBeginCapture(st->cap, hipStreamCaptureModeRelaxed));
-        enqueue_gn_step(p, st->cap, part);
+        for (int k = 0; k < nsteps; ++k) enqueue_gn_step(p, st->cap, part);
         HC(hipStreamEndCapture(st->cap, &p->graph));
         HC(hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0));
         p->g_l = p->sp.lIterations;
         p->g_nb = p->nb;
         p->g_res = res_now;
         p->g_maxn = maxn_now;
+        p->g_steps = nsteps;
+        p->g_ns = ns_now;
     }
     HC(hipGraphLaunch(p->gexec, st->stream));
 }
@@ -1037,6 +1056,22 @@ static int plan_step(Opt_Plan* p)
     }
     if (p->st->timing && p->st->verbosity > 0) p->st->ktimer.report();
     return 0;
+}
+
+// Frame solver, quiet: all remaining Gauss-Newton steps of the ramp step as ONE graph launch (nothing on the host looks
+// at a step's result before the next: the cost is wanted after the last one at most, lazy_cost).  False: not applicable,
+// the caller steps one by one.
+static bool plan_steps_batched(Opt_Plan* p)
+{
+    const int n = p->sp.nIterations - p->sp.nIter;
+    if (!p->res_frames || !p->lazy_cost || p->st->verbosity > 0 || !p->st->use_graph || p->st->timing || n < 2 ||
+        !plan_resident_eligible(p))
+        return false;
+    plan_upload_slots(p);
+    plan_gn_step(p, n);
+    if (p->cost_wanted) plan_cost(p, p->sp.nIterations);
+    p->sp.nIter = p->sp.nIterations;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1605,7 +1640,8 @@ static void solver_enqueue(ArapFlow_Solver* s)
         p->lazy_cost = true;
         p->cost_wanted = i + 1 == numIter;
         plan_init(p);
-        while (plan_step(p) != 0) {}
+        if (!plan_steps_batched(p))
+            while (plan_step(p) != 0) {}
     }
     if (s->a_warp) solver_enqueue_warp(s, nframes);
     if (p->res_capable) {
