@@ -125,7 +125,12 @@ __global__ __launch_bounds__(256) void k_analyse(PlanDev pd, uint8_t* tile_activ
 
 // ------------------------------------------------------------------------------------------------
 // PCGInit1: delta = 0; (g, D) = evalJTF; r = -g; pre = guardedInvert(D); p = pre*r; rho0 += r.p
-__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
+// RESF (frame solver in front of a resident launch): UrShape is the pixel grid the library itself wrote (k_frame_reset),
+// so d = U(c) - U(n) is -1 / +1 / +0 exactly and is not loaded; and what the resident kernel does not read -- delta (it
+// starts from zero in registers and writes its own result), M^-1 of the Offset components (it derives them from the
+// flags) -- is not stored: 28 of ~85 bytes per vertex less.
+template <bool RESF>
+__device__ __forceinline__ void gn_init_body(const PlanDev& pd)
 {
     const VIdx v = vidx(pd);
     double* const rho0 = pd.red + ((size_t)v.b * pd.nslots + 0) * NSHARD;
@@ -139,7 +144,9 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
         const size_t gb = (size_t)v.b * pd.N;
         const float2 csi = pd.cs[v.g];
         const float ci = csi.x, si = csi.y;
-        const float2 Oi = sl.O[v.i], Ui = sl.U[v.i];
+        const float2 Oi = sl.O[v.i];
+        float2 Ui = make_float2(0.f, 0.f);
+        if (!RESF) Ui = sl.U[v.i];
         float gx = 0.f, gy = 0.f, ga = 0.f, dO = 0.f, dA = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -147,8 +154,15 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
             const int n = v.i + noff(s, pd.W);
             const float2 csn = pd.cs[gb + n];
             const float cn = csn.x, sn = csn.y;
-            const float2 On = sl.O[n], Un = sl.U[n];
-            const float dx = Ui.x - Un.x, dy = Ui.y - Un.y;
+            const float2 On = sl.O[n];
+            float dx, dy;
+            if (RESF) {
+                dx = s == 0 ? -1.0f : (s == 1 ? 1.0f : 0.0f);          // x - (x + 1), x - (x - 1), x - x
+                dy = s == 2 ? -1.0f : (s == 3 ? 1.0f : 0.0f);
+            } else {
+                const float2 Un = sl.U[n];
+                dx = Ui.x - Un.x; dy = Ui.y - Un.y;
+            }
             const float ox = Oi.x - On.x, oy = Oi.y - On.y;
             const float ex = wr * (ox - fmaf(ci, dx, -(si * dy)));
             const float ey = wr * (oy - fmaf(si, dx, ci * dy));
@@ -171,21 +185,26 @@ __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd)
         const float rx = -gx, ry = -gy, ra = -ga;
         const float mo = ginv(dOf), ma = ginv(dA);
         const float px = mo * rx, py = mo * ry, pa = ma * ra;
-        pd.deltaO[v.g] = make_float2(0.f, 0.f);
-        pd.deltaA[v.g] = 0.f;
+        if (!RESF) {
+            pd.deltaO[v.g] = make_float2(0.f, 0.f);
+            pd.deltaA[v.g] = 0.f;
+            pd.preO[v.g] = make_float2(mo, mo);
+        }
         pd.rO[v.g] = make_float2(rx, ry);
         pd.rA[v.g] = ra;
-        pd.preO[v.g] = make_float2(mo, mo);
         pd.preA[v.g] = ma;
         pd.pO0[v.g] = make_float2(px, py);
         pd.pA0[v.g] = pa;
         d = (double)dot3(rx, ry, ra, px, py, pa);
-    } else if (v.in) {
+    } else if (v.in && !RESF) {
         pd.preO[v.g] = make_float2(0.f, 0.f);   // PCGInit1 stores pre = 0 on excluded vertices (:395)
         pd.preA[v.g] = 0.f;
     }
     block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, d, 0.0, rho0, nullptr);
 }
+
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init(PlanDev pd) { gn_init_body<false>(pd); }
+__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_init_resf(PlanDev pd) { gn_init_body<true>(pd); }
 
 // ------------------------------------------------------------------------------------------------
 // Iteration l, phase A.  p_l = (l == 0) ? p_init : z + beta * p_{l-1}, with

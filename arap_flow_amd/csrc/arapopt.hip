@@ -889,7 +889,9 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s, int part = GN_STEP_ALL)
     }
     if (part != GN_STEP_FUSED) LAUNCH(p, s, "GNPrep", k_gn_prep, gl, b, pd);
     if (part == GN_STEP_PREP) return;
-    LAUNCH(p, s, "PCGInit1", k_gn_init, gl, b, pdl);
+    // (frame solver on the resident path: no UrShape loads, no stores of what the resident kernel does not read)
+    if (part == GN_STEP_FUSED) LAUNCH(p, s, "PCGInit1", k_gn_init_resf, gl, b, pdl);
+    else LAUNCH(p, s, "PCGInit1", k_gn_init, gl, b, pdl);
     if (res) {
         // all L iterations in one launch, state on chip (arap_resident.h)
         ResDev rd = p->rd;
