@@ -6,7 +6,7 @@
 //   k_gn_init    : PCGInit1 (:361-397)
 //   k_pcg_a      : PCGStep3 of the previous iteration (:537-550) fused with PCGStep1 (:421-434)
 //   k_pcg_b      : PCGStep2 (:446-489)
-//   k_gn_update  : PCGLinearUpdate (:552-557)    (k_gn_update_prep: ... and the next step's k_gn_prep, frame solver)
+//   k_gn_update  : PCGLinearUpdate (:552-557)    (frame solver: done by the resident launch itself, ResDev::fuse_update)
 //   k_cost       : computeCost (:580-592)
 // Launch shape: workgroup = 64 x 4 threads (4 wavefronts, each 64 consecutive x of one row),
 // grid = (ceil(W/64), ceil(H/4), batch); one thread per mesh vertex.
@@ -55,16 +55,11 @@ __device__ __forceinline__ VIdx vidx(const PlanDev& pd)
 }
 
 // ------------------------------------------------------------------------------------------------
-// FLAGS = false: Mask and Constraints are as the last full pass saw them (between two steps of the frame solver): only
-// cos/sin of the new Angle and the zeroing are due
-template <bool FLAGS>
 __device__ __forceinline__ void gn_prep_body(const PlanDev& pd, const VIdx& v)
 {
     const Slot sl = pd.slots[v.b];
     unsigned f = 0;
-    if (!FLAGS) {
-        if (v.in) pd.cs[v.g] = sincos_spec(sl.A[v.i]);
-    } else if (v.in) {
+    if (v.in) {
         const int W = pd.W, H = pd.H;
         const bool act = sl.M[v.i] == 0.0f;
         if (act) {
@@ -79,11 +74,9 @@ __device__ __forceinline__ void gn_prep_body(const PlanDev& pd, const VIdx& v)
         pd.flags[v.g] = (uint8_t)f;
         pd.cs[v.g] = sincos_spec(sl.A[v.i]);
     }
-    if (FLAGS) {
-        const int any = __syncthreads_or((int)(f & F_ACT));
-        if (v.tile_ok && threadIdx.x == 0 && threadIdx.y == 0)
-            pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
-    }
+    const int any = __syncthreads_or((int)(f & F_ACT));
+    if (v.tile_ok && threadIdx.x == 0 && threadIdx.y == 0)
+        pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg] = any ? 1 : 0;
     if (pd.res_gran_n) {
         const int t = threadIdx.y * TILE_X + threadIdx.x;
         if (v.lb == 0 && t < NSHARD) pd.red[(size_t)v.b * pd.nslots * NSHARD + t] = 0.0;
@@ -95,7 +88,7 @@ __device__ __forceinline__ void gn_prep_body(const PlanDev& pd, const VIdx& v)
 
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_prep(PlanDev pd)
 {
-    gn_prep_body<true>(pd, vidx(pd));
+    gn_prep_body(pd, vidx(pd));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -133,6 +126,13 @@ template <bool RESF>
 __device__ __forceinline__ void gn_init_body(const PlanDev& pd)
 {
     const VIdx v = vidx(pd);
+    // (frame solver: the granules of the resident launches that follow (every workgroup of the launch takes its share, before any leaves) -- tags restart at 1 in every launch; k_gn_prep does
+    //  this where it runs)
+    if (RESF && pd.res_gran_n && v.b == 0) {
+        const int t = threadIdx.y * TILE_X + threadIdx.x;
+        for (int i = (int)v.lb * (TILE_X * TILE_Y) + t; i < pd.res_gran_n; i += (int)v.nlb * (TILE_X * TILE_Y))
+            pd.res_gran[i] = 0ull;
+    }
     double* const rho0 = pd.red + ((size_t)v.b * pd.nslots + 0) * NSHARD;
     // (a workgroup with nothing to do still reports to the order-fixed sum: arap_device.h, block_reduce_fixed)
     if (!pd.tileact[(size_t)v.b * pd.tilesX * pd.tilesY + v.wg]) { block_reduce_fixed<1>(pd, v.b, v.lb, v.nlb, 0.0, 0.0, rho0, nullptr); return; }
@@ -434,16 +434,6 @@ __device__ __forceinline__ void gn_update_body(const PlanDev& pd, const VIdx& v,
 __global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update(PlanDev pd, int lag_l)
 {
     gn_update_body(pd, vidx(pd), lag_l);
-}
-
-// Frame solver on the resident path: the update of one Gauss-Newton step and the preparation of the next (cos/sin of the
-// new Angle, zeroed granules; the flags stand: Mask and Constraints change only with the ramp) in one pass over the active tiles -- every vertex's update feeds only its own
-// cos/sin.  (The drop-in path keeps them apart: its caller may change Mask / Constraints between two steps, Opt.h:58-66.)
-__global__ __launch_bounds__(TILE_X* TILE_Y) void k_gn_update_prep(PlanDev pd)
-{
-    const VIdx v = vidx(pd);
-    gn_update_body(pd, v, -1);
-    gn_prep_body<false>(pd, v);
 }
 
 // ------------------------------------------------------------------------------------------------

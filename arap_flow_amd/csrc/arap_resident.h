@@ -147,6 +147,7 @@ struct ResDev {
     int flat_runs;              // groups of up to this many XCD runs use group_sum_x (ARAPOPT_FLAT_RUNS, default RES_FLAT_MAX_RUNS)
     int nowait;                 // diagnostic (ARAPOPT_RES_NOWAIT=1): one sweep per group wait, whatever the tags say (results are garbage:
                                 // measures the iteration without the waits, tools/res_stamps.py)
+    int fuse_update;            // frame solver: the epilogue applies the step (X += delta, cos/sin of the new Angle) itself: no k_gn_update
     unsigned long long* stamps; // diagnostic build only (STAMPS = true): [RES_WGS][16] summed s_memrealtime ticks / clocks
 };
 
@@ -1046,7 +1047,10 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         o[0] = tA; o[1] = tS1; o[2] = tB; o[3] = tS2; o[4] = tU; o[5] = (unsigned long long)tp; { unsigned pc = 0; for (int q = 0; q < 16; ++q) pc += __popc(nbits[q]); o[6] = (unsigned long long)nh | ((unsigned long long)pc << 32) | ((unsigned long long)*nremote << 48); } o[7] = (fast ? 1ull : 0ull) | (zfast ? 2ull : 0ull) | (hier ? 4ull : 0ull) | (subfast ? 8ull : 0ull);
     }
     if (!alive) return;
-    // ---- epilogue: the last iteration's delta += alpha p, then delta back to the plan images for k_gn_update ----
+    // ---- epilogue: the last iteration's delta += alpha p; then the step itself -- PCGLinearUpdate (:552-557) and the cos/sin
+    // of the new Angle, what k_gn_update and the next step's k_gn_prep would do -- for the frame solver (rd.fuse_update: a
+    // failed launch there is followed by a redo of the whole schedule from the reset, never by a step on stale unknowns),
+    // or delta back to the plan images for k_gn_update (drop-in plans: a launch that gave up must leave X untouched) ----
     if (L > 0) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
@@ -1060,6 +1064,30 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     int lo = loff;
     asm volatile("" : "+v"(lo));       // (else the nine store addresses are formed before the loop and spilled)
+    if (rd.fuse_update) {
+        const Slot sl = pd.slots[b];
+        float2 o_[NS];
+        float a_[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            o_[j] = make_float2(0.f, 0.f); a_[j] = 0.f;
+            if (fl[j] & F_ACT) { const int i = ibase[j] + lo; o_[j] = sl.O[i]; a_[j] = sl.A[i]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (fl[j] & F_ACT) {
+                const int i = ibase[j] + lo;
+                float2 o = o_[j];
+                o.x = o.x + dx_[j];
+                o.y = o.y + dy_[j];
+                const float a = a_[j] + da_[j];
+                sl.O[i] = o;
+                sl.A[i] = a;
+                pd.cs[gb + i] = sincos_spec(a);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
         const unsigned f = fl[j];

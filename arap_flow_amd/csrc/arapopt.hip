@@ -160,7 +160,7 @@ struct Opt_Plan {
     unsigned res_launches = 0;
     // drop-in (Opt_*) plans: result of the Init-time analysis (k_analyse) of the caller's Mask / UrShape
     bool opt_res_ok = false;
-    bool prep_done = false;         // the last enqueued step left flags / cos-sin / granules ready for the next (k_gn_update_prep)
+    bool prep_done = false;         // the last enqueued step left flags and cos/sin ready for the next (resident launch with fuse_update)
     Slot opt_res_slot{};
     int* d_notgrid = nullptr;
     // "LMGPU" plans
@@ -843,8 +843,9 @@ static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
     }
 }
 
-// Frame solver on the resident path: the update kernel of a step also prepares the next step (k_gn_update_prep), so a
-// step is [init, resident launches, update + prep] and a lone k_gn_prep runs only where no step came before (the first
+// Frame solver on the resident path: the resident launch applies the step itself (X += delta, cos/sin of the new Angle:
+// ResDev::fuse_update) and the init kernel zeroes the granules, so a step is [init, resident launches] and a lone k_gn_prep
+// (flags, tile activity) runs only where no step came before (the first
 // step after the ramp moved the constraints, or after a step on another path): Opt_Plan::prep_done.
 static bool plan_fused_prep(Opt_Plan* p) { return plan_resident_eligible(p) && p->res_frames; }
 
@@ -890,11 +891,13 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s, int part = GN_STEP_ALL)
     if (part != GN_STEP_FUSED) LAUNCH(p, s, "GNPrep", k_gn_prep, gl, b, pd);
     if (part == GN_STEP_PREP) return;
     // (frame solver on the resident path: no UrShape loads, no stores of what the resident kernel does not read)
-    if (part == GN_STEP_FUSED) LAUNCH(p, s, "PCGInit1", k_gn_init_resf, gl, b, pdl);
+    // (... and it zeroes the granules of the launches that follow: pd carries them)
+    if (part == GN_STEP_FUSED) LAUNCH(p, s, "PCGInit1", k_gn_init_resf, gl, b, pd);
     else LAUNCH(p, s, "PCGInit1", k_gn_init, gl, b, pdl);
     if (res) {
         // all L iterations in one launch, state on chip (arap_resident.h)
         ResDev rd = p->rd;
+        rd.fuse_update = part == GN_STEP_FUSED ? 1 : 0;          // frame solver: the launch applies the step itself
         for (int set = 0; set < p->res_sets; ++set) {
             rd.wgmap = p->d_wgmap + (size_t)set * RES_WGS;
             rd.gran = p->rd.gran + gran_per_launch * set;
@@ -919,8 +922,7 @@ static void enqueue_gn_step(Opt_Plan* p, hipStream_t s, int part = GN_STEP_ALL)
     }
     // (the lean streaming schedule leaves the last iteration's delta += alpha p to the update kernel)
     const int lag = (!res && L > 0 && plan_lean_stream(p)) ? L - 1 : -1;
-    if (part == GN_STEP_FUSED) LAUNCH(p, s, "PCGLinearUpdate+GNPrep", k_gn_update_prep, gl, b, pd);
-    else LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl, lag);
+    if (part != GN_STEP_FUSED) LAUNCH(p, s, "PCGLinearUpdate", k_gn_update, gl, b, pdl, lag);
 }
 
 // nsteps consecutive Gauss-Newton steps (one graph launch: between two graphs the GPU idles 8.6 us, inside one 0.2 us
