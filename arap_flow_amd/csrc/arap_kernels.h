@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_analyse(PlanDev pd, uint8_t* tile_activ
 // RESF (frame solver in front of a resident launch): UrShape is the pixel grid the library itself wrote (k_frame_reset),
 // so d = U(c) - U(n) is -1 / +1 / +0 exactly and is not loaded; and what the resident kernel does not read -- delta (it
 // starts from zero in registers and writes its own result), M^-1 of the Offset components (it derives them from the
-// flags) -- is not stored: 28 of ~85 bytes per vertex less.
+// flags; p0 = M^-1 r, which it forms from r) -- is not stored: 40 of ~85 bytes per vertex less.
 template <bool RESF>
 __device__ __forceinline__ void gn_init_body(const PlanDev& pd)
 {
@@ -193,8 +193,10 @@ __device__ __forceinline__ void gn_init_body(const PlanDev& pd)
         pd.rO[v.g] = make_float2(rx, ry);
         pd.rA[v.g] = ra;
         pd.preA[v.g] = ma;
-        pd.pO0[v.g] = make_float2(px, py);
-        pd.pA0[v.g] = pa;
+        if (!RESF) {                                      // (the resident kernel forms p0 = M^-1 r itself)
+            pd.pO0[v.g] = make_float2(px, py);
+            pd.pA0[v.g] = pa;
+        }
         d = (double)dot3(rx, ry, ra, px, py, pa);
     } else if (v.in && !RESF) {
         pd.preO[v.g] = make_float2(0.f, 0.f);   // PCGInit1 stores pre = 0 on excluded vertices (:395)

@@ -547,14 +547,14 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     unsigned long long* const zx_b = rd.zx + (size_t)b * RES_MAX_TILES * RES_ZG;    // this solve's published border z
     for (int c = tid; c < tp * RES_ZG; c += RES_THREADS)
         __hip_atomic_store(zx_b + (size_t)tfirst * RES_ZG + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float2 qC[NS], qR[NS], vP[NS], vC[NS], hP[NS], hC[NS];
-    float qRa[NS], qM[NS], vA[NS], hA[NS];
+    float2 qC[NS], qR[NS], vR[NS], vC[NS], hR[NS], hC[NS];
+    float qRa[NS], qM[NS], vRa[NS], vM[NS], hRa[NS], hM[NS];
     unsigned qF[NS], vF[NS], hF[NS];                   // flags of the own vertex / of the halo vertices this lane fetches
     const int vrow = ly == 0 ? 0 : RT_Y + 1, hcol = lx == 0 ? 0 : RT_X + 1;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-        qC[j] = qR[j] = vP[j] = vC[j] = hP[j] = hC[j] = make_float2(0.f, 0.f);
-        qRa[j] = qM[j] = vA[j] = hA[j] = 0.f;
+        qC[j] = qR[j] = vR[j] = vC[j] = hR[j] = hC[j] = make_float2(0.f, 0.f);
+        qRa[j] = qM[j] = vRa[j] = vM[j] = hRa[j] = hM[j] = 0.f;
         qF[j] = vF[j] = hF[j] = 0u;
         const int org = org_[j];
         const int y0 = org / W, x0 = org - y0 * W;
@@ -562,17 +562,18 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         if (org >= 0 && x < W && y < H) {
             const size_t i = gb + (size_t)(x + W * y);
             qF[j] = pd.flags[i];
-            // (own p0 = M^-1 r is formed below exactly as k_gn_init formed it: 12 bytes per vertex less to fetch)
+            // (p0 = M^-1 r, of the own vertex and of the halo vertices, is formed below exactly as k_gn_init forms it: the
+            //  init kernel in front of a resident launch does not even store it)
             qC[j] = pd.cs[i];
             qR[j] = pd.rO[i]; qRa[j] = pd.rA[i]; qM[j] = pd.preA[i];
             // halo cells this thread is responsible for: above / below its column, left / right of its row
             if ((ly == 0 && y0 > 0) || (ly == RT_Y - 1 && y + 1 < H)) {
                 const size_t hi = ly == 0 ? i - W : i + W;
-                vF[j] = pd.flags[hi]; vP[j] = pd.pO0[hi]; vC[j] = pd.cs[hi]; vA[j] = pd.pA0[hi];
+                vF[j] = pd.flags[hi]; vR[j] = pd.rO[hi]; vRa[j] = pd.rA[hi]; vM[j] = pd.preA[hi]; vC[j] = pd.cs[hi];
             }
             if ((lx == 0 && x0 > 0) || (lx == RT_X - 1 && x + 1 < W)) {
                 const size_t hi = lx == 0 ? i - 1 : i + 1;
-                hF[j] = pd.flags[hi]; hP[j] = pd.pO0[hi]; hC[j] = pd.cs[hi]; hA[j] = pd.pA0[hi];
+                hF[j] = pd.flags[hi]; hR[j] = pd.rO[hi]; hRa[j] = pd.rA[hi]; hM[j] = pd.preA[hi]; hC[j] = pd.cs[hi];
             }
         }
     }
@@ -602,11 +603,13 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
         }
         if (vF[j] & F_ACT) {
             const int hc = vrow * LROW + (lx + 1);
-            TP2(T)[hc] = vP[j]; TCS(T)[hc] = vC[j]; TPA(T)[hc] = vA[j];
+            const float mo = moLUT[__popc(vF[j] & 15u) + 5 * (int)((vF[j] >> 4) & 1u)];
+            TP2(T)[hc] = make_float2(mo * vR[j].x, mo * vR[j].y); TCS(T)[hc] = vC[j]; TPA(T)[hc] = vM[j] * vRa[j];
         }
         if (hF[j] & F_ACT) {
             const int hc = (ly + 1) * LROW + hcol;
-            TP2(T)[hc] = hP[j]; TCS(T)[hc] = hC[j]; TPA(T)[hc] = hA[j];
+            const float mo = moLUT[__popc(hF[j] & 15u) + 5 * (int)((hF[j] >> 4) & 1u)];
+            TP2(T)[hc] = make_float2(mo * hR[j].x, mo * hR[j].y); TCS(T)[hc] = hC[j]; TPA(T)[hc] = hM[j] * hRa[j];
         }
         fl[j] = qF[j];
         ibase[j] = __builtin_amdgcn_readfirstlane(x0 + W * y0);        // uniform: vertex index of the tile origin
