@@ -847,7 +847,9 @@ static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
 // ResDev::fuse_update) and the init kernel zeroes the granules, so a step is [init, resident launches] and a lone k_gn_prep
 // (flags, tile activity) runs only where no step came before (the first
 // step after the ramp moved the constraints, or after a step on another path): Opt_Plan::prep_done.
-static bool plan_fused_prep(Opt_Plan* p) { return plan_resident_eligible(p) && p->res_frames; }
+// (not in a verbose solve: that one checks every step by itself and redoes a failed step alone, which needs the step's
+//  update left undone)
+static bool plan_fused_prep(Opt_Plan* p) { return plan_resident_eligible(p) && p->res_frames && p->st->verbosity == 0; }
 
 // Grid of the list launches (k_gn_prep / k_gn_init / k_gn_update over the frames' active 64x4 tiles): the longest list,
 // rounded up to a multiple of 64 workgroups so that batches of similar frames replay the same captured graph (a
