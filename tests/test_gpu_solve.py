@@ -195,6 +195,32 @@ def test_resident_and_two_kernel_paths_are_bit_identical(gpu_state):
             assert a["cost"] == b["cost"]
 
 
+def test_frame_solver_step_sequencing_quiet_vs_verbose(gpu_state, capfd):
+    """A quiet frame solve runs a Gauss-Newton step as [k_gn_init_resf, resident launch that applies the step itself], all
+    steps of a ramp step in one graph; a verbose one (the state prints the cost after every step) as [k_gn_prep, k_gn_init,
+    resident launch, k_gn_update] step by step.  Same operation list: identical bits, and both on the resident kernel."""
+    from arap_flow_amd import synth
+    W, H, nfr, sched = 320, 200, 3, (3, 3, 40)
+    frames = [synth.make_frame(W, H, seed=70 + s, K=1, fd=2) for s in range(nfr)]
+    outs = []
+    loud = opt.State(verbosity=1)
+    try:
+        for st in (gpu_state, loud):
+            fs = opt.FrameSolver(st, W, H, batch=nfr)
+            for b, f in enumerate(frames):
+                fs.set_frame(b, f["mask_red"], f["constraints"])
+            fs.solve(nfr, *sched)
+            outs.append([fs.results(b, want_rgb=False) for b in range(nfr)])
+            assert fs.stats()["resident_launches"] == sched[0] * sched[1]
+            fs.close()
+    finally:
+        loud.close()
+    assert capfd.readouterr().out.count("cost:") == sched[0] * sched[1]      # (the verbose solve did step one by one)
+    for a, b in zip(*outs):
+        assert np.array_equal(a["offset"], b["offset"]) and np.array_equal(a["angle"], b["angle"])
+        assert a["cost"] == b["cost"]
+
+
 def test_resident_kernel_longest_pcg_loop_and_the_limit_above_it(gpu_state):
     """The border-z granules of the resident kernel carry 16-bit iteration tags (2 l + 3): launches of up to
     RES_MAX_L = 32 000 PCG iterations run on it (tags up to 64 003, bit-identical to the two-kernel path); one
