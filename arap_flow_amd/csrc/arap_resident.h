@@ -761,14 +761,20 @@ __global__ __launch_bounds__(RES_THREADS, 2) void k_pcg_resident(PlanDev pd, Res
     }
     // Wave priorities inside the phases.  The two workgroups of a CU belong to the same solve and run the same phase at
     // the same time; the SIMD's arbiter prefers the OLDER wave, so the CU's second workgroup got what the first left over
-    // (phase A 1.08 vs 1.60 us) -- and the group waits for its slowest member.  Every wave runs the first half of a phase's
-    // slots at high priority and the second half at low priority: whoever is behind is in its high half while the other
-    // is in its low half, and the pair finishes together (phase A 1.18 ... 1.47 us; 5.05 -> 4.84 us per iteration).
-    // (Wave 0 polls the group sums at priority 3, above both.)
+    // (phase A 1.08 vs 1.60 us) -- and the group waits for its slowest member.  Every wave runs the first slots of a phase
+    // at high priority and the last ones at low priority: whoever is behind is in its high part while the other is in its
+    // low part, and the pair finishes together (phase A 1.18 ... 1.47 us; 5.05 -> 4.84 us per iteration with the split
+    // in the middle, round 2).  The split belongs near the END (round 3; high slots of NS, frames/s same box):
+    //   8 frames, NS = 7:          4 / 5 / 6 / 7 of 7 -> 28.47 / 28.65 / 28.63 / 28.25
+    //   24 segment solves, NS = 8: 4 / 6 / 7 / 8 of 8 -> 27.28 / 28.25 / 27.65 / 27.06   (CU mates of different solves)
+    // i.e. the last TWO slots low.  (Wave 0 polls the group sums at priority 3, above both.)
 #ifndef RES_PRIO_HI
 #define RES_PRIO_HI 2
 #endif
-#define RES_PRIO(J) { if (2 * (J) >= NS) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(RES_PRIO_HI); }
+#ifndef RES_PRIO_TAIL
+#define RES_PRIO_TAIL 2     // the last RES_PRIO_TAIL slots of a phase run at low priority, the others at high
+#endif
+#define RES_PRIO(J) { if ((J) + RES_PRIO_TAIL >= NS) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(RES_PRIO_HI); }
 #define RES_PRIO_END() __builtin_amdgcn_s_setprio(0);
     if (STAMPS) t0 = __builtin_amdgcn_s_memrealtime();
     for (int l = 0; l < L && alive; ++l) {
