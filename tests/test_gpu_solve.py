@@ -375,6 +375,34 @@ def test_solver_reuse_across_frames_of_different_tile_counts(gpu_state):
             one.close()
 
 
+def test_solver_reuse_across_batches_of_the_same_shape(gpu_state):
+    """Batch after batch of DIFFERENT frames whose deal has the same shape (launches, slot counts, list length rounded to 64
+    workgroups) replays the captured graph of the first batch: only the tables behind it change.  Each result equals a fresh
+    solver's (a stale table or a baked-in argument would show)."""
+    from arap_flow_amd import synth
+    W, H, nfr, sched = 854, 480, 4, (2, 3, 30)
+    fs = opt.FrameSolver(gpu_state, W, H, batch=nfr)
+    got, sets = [], []
+    for rnd in range(3):
+        frames = [synth.make_frame(W, H, seed=200 + 10 * rnd + s) for s in range(nfr)]
+        sets.append(frames)
+        for b, f in enumerate(frames):
+            fs.set_frame(b, f["mask_red"], f["constraints"])
+        fs.solve(nfr, *sched)
+        got.append([fs.results(b, want_rgb=False) for b in range(nfr)])
+    fs.close()
+    for rnd in (0, 2):
+        one = opt.FrameSolver(gpu_state, W, H, batch=nfr)
+        for b, f in enumerate(sets[rnd]):
+            one.set_frame(b, f["mask_red"], f["constraints"])
+        one.solve(nfr, *sched)
+        for b in range(nfr):
+            r = one.results(b, want_rgb=False)
+            assert np.array_equal(r["offset"], got[rnd][b]["offset"]) and np.array_equal(r["angle"], got[rnd][b]["angle"])
+            assert r["cost"] == got[rnd][b]["cost"]
+        one.close()
+
+
 def test_resident_packing_of_many_uneven_solves(gpu_state):
     """The host deals every solve a group of the resident launch's 512 workgroups sized by its active-tile count and
     packs small solves onto one XCD (arapopt.hip: plan_resident_pack).  48 solves of very different sizes need two
