@@ -845,8 +845,8 @@ static void launch_pcg_a(Opt_Plan* p, hipStream_t s, int l)
 
 // Frame solver on the resident path: the resident launch applies the step itself (X += delta, cos/sin of the new Angle:
 // ResDev::fuse_update) and the init kernel zeroes the granules, so a step is [init, resident launches] and a lone k_gn_prep
-// (flags, tile activity) runs only where no step came before (the first
-// step after the ramp moved the constraints, or after a step on another path): Opt_Plan::prep_done.
+// (flags, tile activity) runs only where no step came before (the first step after the ramp moved the constraints, or
+// after a step on another path): Opt_Plan::prep_done.
 // (not in a verbose solve: that one checks every step by itself and redoes a failed step alone, which needs the step's
 //  update left undone)
 static bool plan_fused_prep(Opt_Plan* p) { return plan_resident_eligible(p) && p->res_frames && p->st->verbosity == 0; }
@@ -862,7 +862,8 @@ static int plan_list_blocks(Opt_Plan* p)
 }
 
 // enqueue the kernels of one Gauss-Newton step (without the cost) on stream s
-// part: GN_STEP_ALL = prep, init, PCG, update;  GN_STEP_PREP = the lone prep;  GN_STEP_FUSED = init, PCG, update + prep
+// part: GN_STEP_ALL = prep, init, PCG, update;  GN_STEP_PREP = the lone prep;  GN_STEP_FUSED = lean init, resident launch(es)
+// that apply the step themselves
 enum { GN_STEP_ALL = 0, GN_STEP_PREP = 1, GN_STEP_FUSED = 2 };
 static void enqueue_gn_step(Opt_Plan* p, hipStream_t s, int part = GN_STEP_ALL)
 {
